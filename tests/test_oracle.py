@@ -1,0 +1,108 @@
+"""CPU: the oracle restatement (oracle/ref_cpu.py) against the golden vectors the
+reference itself produced (oracle/make_golden.py).  No GPU, no /root/reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ref_cpu as R
+
+TOL = 2e-5  # fp32 round-off between two CPU evaluation orders
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).double(); b = torch.as_tensor(b).double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _sd_hash(sd):
+    return R.tensor_sha256(torch.cat([v.reshape(-1) for _, v in sorted(sd.items())]))
+
+
+@pytest.mark.parametrize("name,batch", [("tiny", 4), ("small", 2)])
+def test_model_cross_matches_reference(golden_dir, name, batch):
+    g = np.load(os.path.join(golden_dir, f"model_cross_{name}.npz"))
+    cfg = R.make_config(name)
+    sd = R.make_state_dict(cfg, seed=0)
+    img, labels = R.make_inputs(cfg, batch, seed=0)
+    # the generators must reproduce the tensors the reference was run on
+    assert str(g["img_sha256"]) == R.tensor_sha256(img)
+    assert str(g["sd_sha256"]) == _sd_hash(sd)
+    assert np.array_equal(g["labels"], labels.numpy())
+    cap = {}
+    logits, loss = R.model_cross_forward(sd, img, labels, cfg, capture=cap)
+    assert rel(logits, g["logits"]) < TOL
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    for b in range(cfg.num_multi_blocks):
+        for m in range(cfg.num_modalities):
+            assert rel(cap[f"msb{b}"][m], g[f"msb{b}/mod{m}/full"]) < TOL
+    _, _, grads = R.model_cross_loss_and_grads(sd, img, labels, cfg)
+    for k, gr in grads.items():
+        if k.endswith("wk.bias"):  # identically-zero gradient: round-off only
+            assert float(gr.abs().max()) < 1e-5
+            continue
+        assert abs(float(gr.double().norm()) - float(g[f"gnorm/{k}"])) <= 5e-4 * float(g[f"gnorm/{k}"]) + 1e-9, k
+
+
+def test_blocks_match_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    cfg = R.make_config("small")
+    sd = R.make_state_dict(cfg, seed=3)
+    assert str(g["sd_sha256"]) == _sd_hash(sd)
+    H = cfg.num_heads
+    for N in (17, 65, 130):
+        x = torch.from_numpy(g[f"sab/N{N}/x"])
+        assert rel(R.self_block(sd, "transformer.0.blocks.0.0", x, H), g[f"sab/N{N}/y"]) < TOL
+        assert rel(R.self_attention(sd, "transformer.0.blocks.0.0.attn.fn", x, H), g[f"attn/N{N}/y"]) < TOL
+        assert rel(R.feed_forward(sd, "transformer.0.blocks.0.0.ffn.fn", x), g[f"ffn/N{N}/y"]) < TOL
+        assert rel(R.cross_block(sd, "transformer.0.fusion.0", x, H), g[f"cab/N{N}/y"]) < TOL
+        assert rel(R.cls_cross_attention(sd, "transformer.0.fusion.0.attn.fn", x, H), g[f"xattn/N{N}/y"]) < TOL
+        xr = x.clone().requires_grad_(True)
+        R.self_block(sd, "transformer.0.blocks.0.0", xr, H).square().sum().backward()
+        assert rel(xr.grad, g[f"sab/N{N}/dx"]) < 1e-4
+        xr = x.clone().requires_grad_(True)
+        R.cross_block(sd, "transformer.0.fusion.0", xr, H).square().sum().backward()
+        assert rel(xr.grad, g[f"cab/N{N}/dx"]) < 1e-4
+    xs = [torch.from_numpy(g[f"msb/x{m}"]) for m in range(3)]
+    ys = R.multi_scale_block(sd, "transformer.0", xs, cfg)
+    for m in range(3):
+        assert rel(ys[m], g[f"msb/y{m}"]) < TOL
+
+
+def test_patchify_index_map(golden_dir):
+    g = np.load(os.path.join(golden_dir, "blocks.npz"))
+    vol = torch.arange(2 * 8 * 12 * 6, dtype=torch.float32).reshape(2, 8, 12, 6)
+    assert np.array_equal(R.patchify(vol, (4, 3, 2)).numpy(), g["patchify/out"])
+    # closed form: token t=(h*Wn+w)*Dn+d, feature f=(p1*hp+p2)*wp+p3
+    Dn, Hn, Wn, dp, hp, wp = 2, 4, 3, 4, 3, 2
+    out = R.patchify(vol, (dp, hp, wp))
+    for (b, h, w, d, p1, p2, p3) in [(0, 0, 0, 0, 0, 0, 0), (1, 3, 2, 1, 3, 2, 1), (0, 2, 1, 1, 2, 0, 1)]:
+        assert out[b, (h * Wn + w) * Dn + d, (p1 * hp + p2) * wp + p3] == vol[b, d * dp + p1, h * hp + p2, w * wp + p3]
+
+
+def test_encoder_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "encoder.npz"))
+    sd = R.make_encoder_state_dict(256, 512, 2, seed=5)
+    assert str(g["sd_sha256"]) == _sd_hash(sd)
+    for N in (65, 130):
+        x = torch.from_numpy(g[f"N{N}/x"])
+        assert rel(R.encoder_forward(sd, x, 4, 2), g[f"N{N}/y"]) < TOL
+        xr = x.clone().requires_grad_(True)
+        R.encoder_forward(sd, xr, 4, 2).square().sum().backward()
+        assert rel(xr.grad, g[f"N{N}/dx"]) < 1e-4
+
+
+def test_flop_model_matches_baseline():
+    # BASELINE.md §3 table
+    fwd, both = R.flops_per_sample(R.make_config("base"))
+    assert abs(fwd / 1e9 - 75.910) < 0.01 and abs(both / 1e9 - 221.286) < 0.01
+    fwd, both = R.flops_per_sample(R.make_config("tiny"))
+    assert abs(fwd / 1e9 - 0.137) < 0.001  # 2x2 blocks, 5.66 M params
+    fwd, both = R.flops_per_sample(R.make_config("long"))
+    assert abs(fwd / 1e9 - 921.7) < 0.1
+
+
+def test_base_logits_golden_present(golden_dir):
+    g = np.load(os.path.join(golden_dir, "model_cross_base.npz"))
+    assert g["logits"].shape == (2, 2) and np.isfinite(g["logits"]).all()
