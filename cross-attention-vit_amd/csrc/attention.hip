@@ -1,0 +1,453 @@
+// Fused (flash-style) self-attention for gfx950, head dim 64, bf16 in / fp32 accumulate.
+//
+// All three kernels put the softmax ROW INDEX ON THE MFMA LANE ("swapped" products), so row
+// statistics (max, sum, lse, delta) are lane-local scalars and every second product takes the
+// first product's accumulator directly as its B operand (no LDS round trip, no shuffles):
+//   fwd : S^T = K Q^T   -> P^T (in regs) -> O^T += V^T P^T          lane = query
+//   dQ  : S^T = K Q^T, dP^T = V dO^T -> dS^T -> dQ^T += K^T dS^T    lane = query
+//   dKV : S = Q K^T, dP = dO V^T -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS   lane = key
+// The lane-side operand (Q / dO, or K / V) is loaded once from HBM into registers; the streamed
+// operand tiles (64 rows x 64 d, 8 KiB) arrive by LDS-DMA into a double-buffered, XOR-swizzled
+// image that serves both ds_read_b128 row reads and ds_read_b64_tr_b16 transposed reads
+// conflict-free.  v_mfma_f32_32x32x16_bf16 throughout.  No [N,N] tensor ever reaches HBM; the
+// backward recomputes P from the saved log-sum-exp.  dQ and dK/dV are separate kernels, so no
+// atomics and bit-reproducible gradients.
+#include "xvit_common.h"
+
+namespace xvit {
+
+constexpr int DH = 64;          // head dim
+constexpr int TILE_ROWS = 64;   // streamed rows per iteration
+constexpr int IMG_BYTES = TILE_ROWS * DH * 2;  // 8 KiB
+constexpr float LOG2E = 1.4426950408889634f;
+
+// chunk swizzle for a [rows][128 B] image: conflict-free for b128 row reads and tr reads
+__device__ __forceinline__ int swz_img(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+
+// LDS-DMA loader for one 64x64 bf16 tile whose rows are `stride_n` elements apart in HBM.
+struct TileLoader {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff[2];
+  uint32_t step;
+  // base: element (row 0, col 0) of the streamed matrix for this (b, h); rows_total valid rows
+  __device__ __forceinline__ void init(const bf16* base, int64_t stride_n, int rows_total, int wave, int lane) {
+    rsrc = make_rsrc(base, clamp_bytes(((int64_t)(rows_total - 1) * stride_n + DH) * 2));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = (wave * 2 + j) * 8 + (lane >> 3);  // 8 pieces of 8 rows; wave handles 2
+      const int chunk = (lane & 7) ^ swz_img(row);
+      voff[j] = (uint32_t)(row * stride_n * 2 + chunk * 16);
+    }
+    step = (uint32_t)(TILE_ROWS * stride_n * 2);
+  }
+  __device__ __forceinline__ void issue(XVIT_LDS char* image, int wave, int tile) const {
+    const uint32_t soff = (uint32_t)tile * step;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16(rsrc, image + (wave * 2 + j) * 1024, voff[j], soff);
+  }
+};
+
+// Per-lane LDS offsets for the two read kinds on a [64][128 B] swizzled image.
+struct ImgReader {
+  uint32_t row_off[4];  // b128 row read, per k-step over d (16 each)
+  uint32_t tr_off[2][2];  // tr read, per 32-wide d block, per 8-row half (the swizzle differs)
+  __device__ __forceinline__ void init(int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) row_off[ks] = (uint32_t)(r * 128 + (((ks * 2 + h) ^ swz_img(r)) << 4));
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, hh = g >> 1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int row = 8 * half + 4 * hh + q;
+        const int chunk = db * 4 + 2 * (g & 1) + (p >> 1);
+        tr_off[db][half] = (uint32_t)(row * 128 + ((chunk ^ swz_img(row)) << 4) + 8 * (p & 1));
+      }
+  }
+  // A operand, natural k order: rows rb*32 .. +31 of the image, k = d in [16ks, 16ks+16)
+  __device__ __forceinline__ bf16x8 row_frag(const XVIT_LDS char* img, int rb, int ks) const {
+    return *(const XVIT_LDS bf16x8*)(img + row_off[ks] + rb * 32 * 128);
+  }
+  // A operand = image^T: output rows d in [32db, 32db+32), k = image rows rb*32 + 16s + {accumulator order}
+  __device__ __forceinline__ bf16x8 tr_frag(const XVIT_LDS char* img, int db, int rb, int s) const {
+    const int base = (rb * 32 + 16 * s) * 128;  // +16/+32 rows leave the swizzle unchanged
+    const s16x4 lo = lds_read_tr16(img + tr_off[db][0] + base);
+    const s16x4 hi = lds_read_tr16(img + tr_off[db][1] + base);
+    s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+
+// registers 8s..8s+7 of a 32x32 accumulator as the bf16 B operand of k-step s
+__device__ __forceinline__ bf16x8 acc_frag(const f32x16& x, int s) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = f2bf(x[8 * s + j]);
+  return o;
+}
+
+// Lane-side operand: 32 rows (one per lane&31) x 64 d from HBM into 4 B-operand fragments.
+__device__ __forceinline__ void load_lane_operand(bf16x8 (&f)[4], const bf16* base, int64_t stride_n, int row0, int rows_total, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = make_rsrc(base, clamp_bytes(((int64_t)(rows_total - 1) * stride_n + DH) * 2));
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    f[ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, (uint32_t)(((int64_t)(row0 + r) * stride_n + ks * 16 + h * 8) * 2), 0, 0));
+  }
+}
+
+// element index inside a 32-row accumulator block held in register i by lane half h
+__device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+// store a [64 d][32 rows-on-lane] accumulator pair as bf16 rows of a [*, stride_n] matrix
+__device__ __forceinline__ void store_lane_rows(const f32x16 (&acc)[2], float mul, bf16* base, int64_t stride_n, int row, bool valid, int lane) {
+  if (!valid) return;
+  const int h = lane >> 5;
+  bf16* dst = base + (int64_t)row * stride_n;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = f2bf(acc[db][g * 4 + e] * mul);
+      *(bf16x4*)(dst + db * 32 + 8 * g + 4 * h) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                          int64_t sb, int64_t sn, bf16* __restrict__ o, int64_t osb, int64_t osn,
+                                                          float* __restrict__ lse, int H, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;  // [2 stages][K image | V image]
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int64_t off = (int64_t)b * sb + head * DH;
+  const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+
+  TileLoader lk, lv;
+  lk.init(k + off, sn, N, wave, lane);
+  lv.init(v + off, sn, N, wave, lane);
+  lk.issue(smem, wave, 0);
+  lv.issue(smem + IMG_BYTES, wave, 0);
+
+  bf16x8 qf[4];
+  load_lane_operand(qf, q + off, sn, q0, N, lane);
+  ImgReader rd;
+  rd.init(lane);
+
+  const int h = lane >> 5;
+  const float c = scale * LOG2E;
+  float m_run = -INFINITY, l_run = 0.f;
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      XVIT_LDS char* nxt = smem + ((t + 1) & 1) * 2 * IMG_BYTES;
+      lk.issue(nxt, wave, t + 1);
+      lv.issue(nxt + IMG_BYTES, wave, t + 1);
+    }
+    const XVIT_LDS char* kimg = smem + (t & 1) * 2 * IMG_BYTES;
+    const XVIT_LDS char* vimg = kimg + IMG_BYTES;
+
+    // S^T[key][query] = K Q^T
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, kb, ks), qf[ks], s[kb], 0, 0, 0);
+    }
+    if (t == ntiles - 1 && (N & (TILE_ROWS - 1))) {  // mask the keys past N
+      const int kbase = t * TILE_ROWS;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kbase + kb * 32 + acc_row(i, h) >= N) s[kb][i] = -INFINITY;
+    }
+    // online softmax; the query is this lane's column, split over the two lane halves
+    float mx = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][i], c, -mc));
+        s[kb][i] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+    // O^T[d][query] += V^T P^T
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = acc_frag(s[kb], ss);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(vimg, db, kb, ss), pf, oacc[db], 0, 0, 0);
+      }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const int qrow = q0 + (lane & 31);
+  const bool valid = qrow < N;
+  if (valid && h == 0) lse[((int64_t)b * H + head) * N + qrow] = m_run * scale + __logf(l_tot);
+  store_lane_rows(oacc, 1.0f / l_tot, o + (int64_t)b * osb + head * DH, osn, qrow, valid, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// delta[b,h,n] = sum_d dO * O
+// ------------------------------------------------------------------------------------------
+__global__ void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb, int64_t osn, float* __restrict__ delta,
+                                  int H, int N, int total) {
+  // 8 lanes per (b, h, n) row: each 16 B of O and dO
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rowid = gid >> 3, part = gid & 7;
+  float acc = 0.f;
+  if (rowid < total) {
+    const int n = rowid % N, bh = rowid / N, head = bh % H, b = bh / H;
+    const int64_t off = (int64_t)b * osb + (int64_t)n * osn + head * DH + part * 8;
+    const bf16x8 a = *(const bf16x8*)(o + off), g = *(const bf16x8*)(d_o + off);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += bf2f(a[e]) * bf2f(g[e]);
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  if (rowid < total && part == 0) delta[rowid] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, dQ: one wave = 32 queries, streams K and V tiles
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                             int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             bf16* __restrict__ dq, int H, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int64_t off = (int64_t)b * sb + head * DH;
+  const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+
+  TileLoader lk, lv;
+  lk.init(k + off, sn, N, wave, lane);
+  lv.init(v + off, sn, N, wave, lane);
+  lk.issue(smem, wave, 0);
+  lv.issue(smem + IMG_BYTES, wave, 0);
+
+  bf16x8 qf[4], dof[4];
+  load_lane_operand(qf, q + off, sn, q0, N, lane);
+  load_lane_operand(dof, d_o + (int64_t)b * osb + head * DH, osn, q0, N, lane);
+  ImgReader rd;
+  rd.init(lane);
+
+  const int qrow = q0 + (lane & 31);
+  const bool valid = qrow < N;
+  const int64_t stat = ((int64_t)b * H + head) * N + qrow;
+  const float c = scale * LOG2E;
+  // invalid query rows: lse = +big -> P = 0, so nothing is accumulated for them
+  const float nlse = valid ? -lse[stat] * LOG2E : -1e30f;
+  const float dlt = valid ? delta[stat] : 0.f;
+
+  f32x16 dqacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      XVIT_LDS char* nxt = smem + ((t + 1) & 1) * 2 * IMG_BYTES;
+      lk.issue(nxt, wave, t + 1);
+      lv.issue(nxt + IMG_BYTES, wave, t + 1);
+    }
+    const XVIT_LDS char* kimg = smem + (t & 1) * 2 * IMG_BYTES;
+    const XVIT_LDS char* vimg = kimg + IMG_BYTES;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, kb, ks), qf[ks], s, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(vimg, kb, ks), dof[ks], dp, 0, 0, 0);
+      // keys past N have K = V = 0 (zero-filled by the DMA), so they add nothing to dQ
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[i], c, nlse));
+        s[i] = pv * (dp[i] - dlt);  // dS^T
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 dsf = acc_frag(s, ss);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(kimg, db, kb, ss), dsf, dqacc[db], 0, 0, 0);
+      }
+    }
+  }
+  store_lane_rows(dqacc, scale, dq + off, sn, qrow, valid, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward, dK/dV: one wave = 32 keys, streams Q and dO tiles (+ lse, delta)
+// ------------------------------------------------------------------------------------------
+constexpr int DKV_STAGE = 2 * IMG_BYTES + 512;  // Q image | dO image | -lse*log2e[64] | delta[64]
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                              int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int H, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
+  const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
+  const int b = blockIdx.z, head = blockIdx.y;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int64_t off = (int64_t)b * sb + head * DH;
+  const int64_t ooff = (int64_t)b * osb + head * DH;
+  const int64_t stat0 = ((int64_t)b * H + head) * N;
+  const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+
+  TileLoader lq, ldo;
+  lq.init(q + off, sn, N, wave, lane);
+  ldo.init(d_o + ooff, osn, N, wave, lane);
+  auto stage_stats = [&](XVIT_LDS char* st, int tile) {
+    // 128 threads: [0,64) -> -lse*log2e, [64,128) -> delta, for the tile's 64 query rows
+    const int tid = threadIdx.x;
+    if (tid < 128) {
+      const int qi = tile * TILE_ROWS + (tid & 63);
+      float val;
+      if (tid < 64) val = qi < N ? -lse[stat0 + qi] * LOG2E : -1e30f;
+      else val = qi < N ? delta[stat0 + qi] : 0.f;
+      ((XVIT_LDS float*)(st + 2 * IMG_BYTES))[tid] = val;
+    }
+  };
+  lq.issue(smem, wave, 0);
+  ldo.issue(smem + IMG_BYTES, wave, 0);
+  stage_stats(smem, 0);
+
+  bf16x8 kf[4], vf[4];
+  load_lane_operand(kf, k + off, sn, k0, N, lane);
+  load_lane_operand(vf, v + off, sn, k0, N, lane);
+  ImgReader rd;
+  rd.init(lane);
+  const int h = lane >> 5;
+  const float c = scale * LOG2E;
+
+  f32x16 dkacc[2], dvacc[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
+
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < ntiles) {
+      XVIT_LDS char* nxt = smem + ((t + 1) & 1) * DKV_STAGE;
+      lq.issue(nxt, wave, t + 1);
+      ldo.issue(nxt + IMG_BYTES, wave, t + 1);
+      stage_stats(nxt, t + 1);
+    }
+    const XVIT_LDS char* qimg = smem + (t & 1) * DKV_STAGE;
+    const XVIT_LDS char* doimg = qimg + IMG_BYTES;
+    const XVIT_LDS float* st_lse = (const XVIT_LDS float*)(qimg + 2 * IMG_BYTES);
+    const XVIT_LDS float* st_dlt = st_lse + 64;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      // S[query][key] = Q K^T ; dP[query][key] = dO V^T   (key on the lane)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(qimg, qb, ks), kf[ks], s, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(doimg, qb, ks), vf[ks], dp, 0, 0, 0);
+      f32x16 pr;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 nl = *(const XVIT_LDS f32x4*)(st_lse + qb * 32 + 8 * g + 4 * h);
+        const f32x4 dl = *(const XVIT_LDS f32x4*)(st_dlt + qb * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[g * 4 + e], c, nl[e]));
+          pr[g * 4 + e] = pv;
+          s[g * 4 + e] = pv * (dp[g * 4 + e] - dl[e]);  // dS
+        }
+      }
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = acc_frag(pr, ss), dsf = acc_frag(s, ss);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(doimg, db, qb, ss), pf, dvacc[db], 0, 0, 0);
+          dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(qimg, db, qb, ss), dsf, dkacc[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+  const int krow = k0 + (lane & 31);
+  const bool valid = krow < N;
+  store_lane_rows(dkacc, scale, dk + off, sn, krow, valid, lane);
+  store_lane_rows(dvacc, 1.0f, dv + off, sn, krow, valid, lane);
+}
+
+}  // namespace xvit
+
+using namespace xvit;
+
+static int attn_check(const char* who, int B, int H, int N, int dh, int64_t sb, int64_t sn, int64_t osb, int64_t osn) {
+  XVIT_REQUIRE(dh == DH, "%s: head dim %d unsupported (only 64)", who, dh);
+  XVIT_REQUIRE(B > 0 && H > 0 && N > 0 && B <= 65535 && H <= 65535, "%s: bad B/H/N (%d,%d,%d)", who, B, H, N);
+  XVIT_REQUIRE(sn % 8 == 0 && sb % 8 == 0 && osn % 8 == 0 && osb % 8 == 0, "%s: strides must be multiples of 8 elements", who);
+  XVIT_REQUIRE((int64_t)N * sn * 2 < (1ll << 31) && (int64_t)N * osn * 2 < (1ll << 31), "%s: one batch slice exceeds 2 GiB", who);
+  return XVIT_OK;
+}
+
+extern "C" int xvit_attn_fwd(const void* q, const void* k, const void* v, int64_t sb, int64_t sn, void* o, int64_t osb, int64_t osn, float* lse,
+                             int B, int H, int N, int dh, float scale, xvit_stream_t stream) {
+  XVIT_REQUIRE(q && k && v && o && lse, "xvit_attn_fwd: null pointer");
+  if (int e = attn_check("xvit_attn_fwd", B, H, N, dh, sb, sn, osb, osn)) return e;
+  const dim3 grid((N + 127) / 128, H, B), block(256);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 4 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+                     (bf16*)o, osb, osn, lse, H, N, scale);
+  return check_launch("xvit_attn_fwd");
+}
+
+extern "C" int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t sb, int64_t sn, const void* o, const void* d_o, int64_t osb,
+                             int64_t osn, const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int N, int dh, float scale,
+                             xvit_stream_t stream) {
+  XVIT_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "xvit_attn_bwd: null pointer");
+  if (int e = attn_check("xvit_attn_bwd", B, H, N, dh, sb, sn, osb, osn)) return e;
+  hipStream_t s = (hipStream_t)stream;
+  const int total = B * H * N;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, osb, osn, delta, H, N, total);
+  const dim3 grid((N + 127) / 128, H, B), block(256);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 2 * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
+                     osn, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 4 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb, osn,
+                     lse, delta, (bf16*)dq, H, N, scale);
+  return check_launch("xvit_attn_bwd");
+}

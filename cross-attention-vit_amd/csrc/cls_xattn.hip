@@ -1,0 +1,189 @@
+// CLS-query cross-attention (reference model_cross.py:91-99): ONE query row per (batch, head)
+// against N keys/values.  1xN per head is a GEMV, not an MFMA shape: the kernel is bound by the
+// single pass over K and V (2*N*64*2 bytes per (b,h)), so everything is 16-byte coalesced loads
+// straight to registers (8 lanes cover one 128-byte key row), wave shuffles and one LDS score row.
+#include "xvit_common.h"
+
+namespace xvit {
+
+constexpr int XA_THREADS = 256;
+constexpr int XA_DH = 64;
+
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* red /*[4]*/) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = red[0];
+#pragma unroll
+  for (int w = 1; w < XA_THREADS / 64; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+  return r;
+}
+
+// dot of this thread's 8 dims of a (loaded once) with the 8 dims of row n of mat; 8 lanes per row
+__device__ __forceinline__ float row_dot8(const float (&a)[8], const bf16* mat, int64_t stride_n, int n, int part) {
+  const bf16x8 kv = *(const bf16x8*)(mat + (int64_t)n * stride_n + part * 8);
+  float acc = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc = fmaf(a[e], bf2f(kv[e]), acc);
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  acc += __shfl_xor(acc, 4);
+  return acc;
+}
+
+__global__ __launch_bounds__(XA_THREADS) void cls_xattn_fwd_kernel(const bf16* __restrict__ q, int64_t ldq, const bf16* __restrict__ k,
+                                                                   const bf16* __restrict__ v, int64_t sb, int64_t sn, bf16* __restrict__ o,
+                                                                   int64_t ldo, float* __restrict__ p, int H, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sc = (float*)smem_raw;            // [N] scores -> probabilities
+  float* red = sc + ((N + 3) & ~3);        // [4] + [32][64] partial outputs
+  float* part_o = red + 4;
+  const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int part = tid & 7, slice = tid >> 3;  // 32 row slices x 8 lanes
+  const bf16* kb = k + (int64_t)b * sb + head * XA_DH;
+  const bf16* vb = v + (int64_t)b * sb + head * XA_DH;
+
+  float qv[8];
+  {
+    const bf16x8 t = *(const bf16x8*)(q + (int64_t)b * ldq + head * XA_DH + part * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = bf2f(t[e]);
+  }
+  float mx = -INFINITY;
+  for (int n = slice; n < N; n += 32) {
+    const float s = row_dot8(qv, kb, sn, n, part) * scale;
+    if (part == 0) sc[n] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = block_reduce(mx, true, red);
+  float sum = 0.f;
+  for (int n = tid; n < N; n += XA_THREADS) {
+    const float e = __expf(sc[n] - mx);
+    sc[n] = e;
+    sum += e;
+  }
+  sum = block_reduce(sum, false, red);
+  const float inv = 1.0f / sum;
+  float* prow = p + ((int64_t)b * H + head) * N;
+  for (int n = tid; n < N; n += XA_THREADS) {
+    const float pr = sc[n] * inv;
+    sc[n] = pr;
+    prow[n] = pr;
+  }
+  __syncthreads();
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int n = slice; n < N; n += 32) {
+    const bf16x8 vv = *(const bf16x8*)(vb + (int64_t)n * sn + part * 8);
+    const float pr = sc[n];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaf(pr, bf2f(vv[e]), acc[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part_o[slice * 64 + part * 8 + e] = acc[e];
+  __syncthreads();
+  if (tid < 64) {
+    float r = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) r += part_o[s * 64 + tid];
+    o[(int64_t)b * ldo + head * XA_DH + tid] = f2bf(r);
+  }
+}
+
+__global__ __launch_bounds__(XA_THREADS) void cls_xattn_bwd_kernel(const bf16* __restrict__ q, int64_t ldq, const bf16* __restrict__ k,
+                                                                   const bf16* __restrict__ v, int64_t sb, int64_t sn,
+                                                                   const float* __restrict__ p, const bf16* __restrict__ d_o, int64_t lddo,
+                                                                   float* __restrict__ dq, int64_t lddq, bf16* __restrict__ dk,
+                                                                   bf16* __restrict__ dv, int H, int N, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* ds = (float*)smem_raw;            // [N] dp -> ds
+  float* red = ds + ((N + 3) & ~3);
+  float* part_q = red + 4;                 // [32][64]
+  const int head = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int part = tid & 7, slice = tid >> 3;
+  const int64_t boff = (int64_t)b * sb + head * XA_DH;
+  const float* prow = p + ((int64_t)b * H + head) * N;
+
+  float qv[8], gov[8];
+  {
+    const bf16x8 t = *(const bf16x8*)(q + (int64_t)b * ldq + head * XA_DH + part * 8);
+    const bf16x8 g = *(const bf16x8*)(d_o + (int64_t)b * lddo + head * XA_DH + part * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { qv[e] = bf2f(t[e]); gov[e] = bf2f(g[e]); }
+  }
+  // dp[n] = do . v[n];   dsum = sum_n p[n] dp[n]
+  float dsum = 0.f;
+  for (int n = slice; n < N; n += 32) {
+    const float dp = row_dot8(gov, v + boff, sn, n, part);
+    if (part == 0) { ds[n] = dp; dsum += prow[n] * dp; }
+  }
+  dsum = block_reduce(dsum, false, red);
+  // ds[n] = p (dp - dsum);  dq += scale * ds[n] k[n];  dk[n] = scale * ds[n] q;  dv[n] = p[n] do
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int n = slice; n < N; n += 32) {
+    const float pr = prow[n];
+    const float dsn = pr * (ds[n] - dsum) * scale;
+    const bf16x8 kk = *(const bf16x8*)(k + boff + (int64_t)n * sn + part * 8);
+    bf16x8 okk, ovv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      acc[e] = fmaf(dsn, bf2f(kk[e]), acc[e]);
+      okk[e] = f2bf(dsn * qv[e]);
+      ovv[e] = f2bf(pr * gov[e]);
+    }
+    *(bf16x8*)(dk + boff + (int64_t)n * sn + part * 8) = okk;
+    *(bf16x8*)(dv + boff + (int64_t)n * sn + part * 8) = ovv;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part_q[slice * 64 + part * 8 + e] = acc[e];
+  __syncthreads();
+  if (tid < 64) {
+    float r = 0.f;
+#pragma unroll 8
+    for (int s = 0; s < 32; ++s) r += part_q[s * 64 + tid];
+    dq[(int64_t)b * lddq + head * XA_DH + tid] = r;
+  }
+}
+
+}  // namespace xvit
+
+using namespace xvit;
+
+static size_t xa_lds(int N) { return (size_t)(((N + 3) & ~3) + 4 + 32 * 64) * sizeof(float); }
+
+extern "C" int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t sb, int64_t sn, void* o, int64_t ldo, float* p,
+                                  int B, int H, int N, int dh, float scale, xvit_stream_t stream) {
+  XVIT_REQUIRE(q && k && v && o && p, "xvit_cls_xattn_fwd: null pointer");
+  XVIT_REQUIRE(dh == XA_DH, "xvit_cls_xattn_fwd: head dim %d unsupported (only 64)", dh);
+  XVIT_REQUIRE(B > 0 && H > 0 && N > 0 && B <= 65535, "xvit_cls_xattn_fwd: bad B/H/N");
+  XVIT_REQUIRE(ldq % 8 == 0 && sb % 8 == 0 && sn % 8 == 0, "xvit_cls_xattn_fwd: strides must be multiples of 8 elements");
+  XVIT_REQUIRE(xa_lds(N) <= 160 * 1024, "xvit_cls_xattn_fwd: N=%d too long for the LDS score row", N);
+  const size_t lds = xa_lds(N);
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    (void)hipFuncSetAttribute((const void*)cls_xattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = lds;
+  }
+  hipLaunchKernelGGL(cls_xattn_fwd_kernel, dim3(H, B), dim3(XA_THREADS), lds, (hipStream_t)stream, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, sb,
+                     sn, (bf16*)o, ldo, p, H, N, scale);
+  return check_launch("xvit_cls_xattn_fwd");
+}
+
+extern "C" int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t sb, int64_t sn, const float* p, const void* d_o,
+                                  int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, int B, int H, int N, int dh, float scale,
+                                  xvit_stream_t stream) {
+  XVIT_REQUIRE(q && k && v && p && d_o && dq && dk && dv, "xvit_cls_xattn_bwd: null pointer");
+  XVIT_REQUIRE(dh == XA_DH, "xvit_cls_xattn_bwd: head dim %d unsupported (only 64)", dh);
+  XVIT_REQUIRE(B > 0 && H > 0 && N > 0 && B <= 65535, "xvit_cls_xattn_bwd: bad B/H/N");
+  XVIT_REQUIRE(ldq % 8 == 0 && lddo % 8 == 0 && sb % 8 == 0 && sn % 8 == 0, "xvit_cls_xattn_bwd: strides must be multiples of 8 elements");
+  XVIT_REQUIRE(xa_lds(N) <= 160 * 1024, "xvit_cls_xattn_bwd: N=%d too long for the LDS score row", N);
+  const size_t lds = xa_lds(N);
+  static size_t attr = 0;
+  if (lds > 64 * 1024 && lds > attr) {
+    (void)hipFuncSetAttribute((const void*)cls_xattn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr = lds;
+  }
+  hipLaunchKernelGGL(cls_xattn_bwd_kernel, dim3(H, B), dim3(XA_THREADS), lds, (hipStream_t)stream, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, sb,
+                     sn, p, (const bf16*)d_o, lddo, dq, lddq, (bf16*)dk, (bf16*)dv, H, N, scale);
+  return check_launch("xvit_cls_xattn_bwd");
+}

@@ -1,0 +1,186 @@
+// LayerNorm forward / backward over the fp32 residual stream (HBM-bound).
+// One wave per row, the row held in registers (float4 per lane per 256 columns), so x is read
+// once; the backward also folds in the upstream residual gradient and emits the bf16 copy of
+// dx that the following GEMMs consume.  dgamma/dbeta: per-lane column partials across all rows
+// a wave visits, one LDS cross-wave reduction, one atomic per column per block.
+#include "xvit_common.h"
+
+namespace xvit {
+
+constexpr int LN_WAVES = 4;
+
+template <int V>  // V float4 per lane: d <= 256*V
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x_alt, int64_t ldx,
+                                                               int seq_len, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float eps, bf16* __restrict__ y, int64_t ldy, float* __restrict__ mean,
+                                                               float* __restrict__ rstd, int rows, int d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = d >> 2;  // float4 per row
+  const float inv_d = 1.0f / (float)d;
+  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
+    const float* src = (x_alt && (row % seq_len) == 0) ? x_alt : x;
+    const f32x4* xr = (const f32x4*)(src + (int64_t)row * ldx);
+    f32x4 v[V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + i * 64;
+      v[i] = c < nv ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+    const float mu = wave_sum(s) * inv_d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v[i][e] - mu; ss += t * t; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(ss) * inv_d + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    bf16* yr = y + (int64_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const f32x4 g = ((const f32x4*)gamma)[c], b = ((const f32x4*)beta)[c];
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = f2bf((v[i][e] - mu) * rs * g[e] + b[e]);
+        *(bf16x4*)(yr + c * 4) = o;
+      }
+    }
+  }
+}
+
+template <int V>
+__global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const bf16* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+                                                               const float* __restrict__ x_alt, int64_t ldx, int seq_len,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ dres, int64_t lddres,
+                                                               float* __restrict__ dx, int64_t lddx, bf16* __restrict__ dxb, int64_t lddxb,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int d) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = (float*)smem_raw;  // [LN_WAVES][2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = d >> 2;
+  const float inv_d = 1.0f / (float)d;
+  f32x4 g[V], dg[V], db[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = lane + i * 64;
+    g[i] = c < nv ? ((const f32x4*)gamma)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
+    const float* src = (x_alt && (row % seq_len) == 0) ? x_alt : x;
+    const f32x4* xr = (const f32x4*)(src + (int64_t)row * ldx);
+    const bf16* dyr = dy + (int64_t)row * lddy;
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[V], gy[V];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        const f32x4 xv = xr[c];
+        const bf16x4 dv = *(const bf16x4*)(dyr + c * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float h = (xv[e] - mu) * rs, dyv = bf2f(dv[e]);
+          xh[i][e] = h;
+          gy[i][e] = dyv * g[i][e];
+          dg[i][e] += dyv * h;
+          db[i][e] += dyv;
+          s1 += gy[i][e];
+          s2 += gy[i][e] * h;
+        }
+      } else {
+        xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - m1 - xh[i][e] * m2);
+        if (dres) o += *(const f32x4*)(dres + (int64_t)row * lddres + c * 4);
+        *(f32x4*)(dx + (int64_t)row * lddx + c * 4) = o;
+        if (dxb) {
+          bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+          *(bf16x4*)(dxb + (int64_t)row * lddxb + c * 4) = ob;
+        }
+      }
+    }
+  }
+  // cross-wave reduction of the column partials, then one atomic per column per block
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      *(f32x4*)(red + (wave * 2 + 0) * d + c * 4) = dg[i];
+      *(f32x4*)(red + (wave * 2 + 1) * d + c * 4) = db[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int w = 0; w < LN_WAVES; ++w) { a += red[(w * 2 + 0) * d + c]; b += red[(w * 2 + 1) * d + c]; }
+    unsafeAtomicAdd(dgamma + c, a);
+    unsafeAtomicAdd(dbeta + c, b);
+  }
+}
+
+}  // namespace xvit
+
+using namespace xvit;
+
+static int ln_grid(int rows) {
+  const int want = (rows + LN_WAVES - 1) / LN_WAVES;
+  return want < 2048 ? want : 2048;  // grid-stride beyond 8 blocks/CU
+}
+
+extern "C" int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_len, const float* gamma, const float* beta,
+                                  float eps, void* y, int64_t ldy, float* mean, float* rstd, int rows, int d, xvit_stream_t stream) {
+  XVIT_REQUIRE(x && gamma && beta && y && mean && rstd, "xvit_layernorm_fwd: null pointer");
+  XVIT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 4096, "xvit_layernorm_fwd: need 0 < d <= 4096, d %% 4 == 0 (d=%d rows=%d)", d, rows);
+  XVIT_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d, "xvit_layernorm_fwd: ldx/ldy must be multiples of 4 and >= d");
+  XVIT_REQUIRE(!x_alt || seq_len > 0, "xvit_layernorm_fwd: x_alt needs seq_len > 0");
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(ln_grid(rows)), block(LN_WAVES * 64);
+  bf16* yb = (bf16*)y;
+  if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, mean, rstd, rows, d);
+  else hipLaunchKernelGGL((ln_fwd_kernel<16>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, mean, rstd, rows, d);
+  return check_launch("xvit_layernorm_fwd");
+}
+
+extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len,
+                                  const float* mean, const float* rstd, const float* gamma, const float* dres, int64_t lddres, float* dx,
+                                  int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, int rows, int d,
+                                  xvit_stream_t stream) {
+  XVIT_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "xvit_layernorm_bwd: null pointer");
+  XVIT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 4096, "xvit_layernorm_bwd: need 0 < d <= 4096, d %% 4 == 0 (d=%d rows=%d)", d, rows);
+  XVIT_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0) && (!dxb || lddxb % 4 == 0),
+               "xvit_layernorm_bwd: leading dimensions must be multiples of 4");
+  XVIT_REQUIRE(!x_alt || seq_len > 0, "xvit_layernorm_bwd: x_alt needs seq_len > 0");
+  hipStream_t s = (hipStream_t)stream;
+  int g = ln_grid(rows);
+  if (g > 512) g = 512;  // fewer, longer-lived blocks: fewer dgamma/dbeta atomics
+  const dim3 grid(g), block(LN_WAVES * 64);
+  const size_t lds = (size_t)LN_WAVES * 2 * d * sizeof(float);
+  const bf16* dyb = (const bf16*)dy;
+  bf16* dxbb = (bf16*)dxb;
+  if (d <= 1024)
+    hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, rows, d);
+  else
+    hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, rows, d);
+  return check_launch("xvit_layernorm_bwd");
+}

@@ -1,0 +1,280 @@
+// HBM-bound helpers around the GEMMs: 3-D patchify, CLS/pos rows, column sums (bias grads),
+// casts, dropout, the num_classes head and the mean + cross-entropy tail.
+#include "xvit_common.h"
+
+namespace xvit {
+
+// ------------------------------------------------------------------------------------------
+// patchify (reference model_cross.py:193).  Threads walk the INPUT in memory order (8 voxels =
+// one 16/32-byte run each), so reads are fully coalesced; a wave then covers 4 H-rows of 8
+// patches and its writes land as whole 128-byte lines of 8 different token rows.
+// ------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ void patchify_kernel(const T* __restrict__ img, bf16* __restrict__ out, int B, int M, int D, int H, int W, int dp, int hp, int wp,
+                                int64_t total_vec) {
+  const int Wv = W / VEC;
+  const int Dn = D / dp, Wn = W / wp;
+  const int P = Dn * (H / hp) * Wn, pd = dp * hp * wp;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_vec; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int wv = (int)(idx % Wv);
+    int64_t r = idx / Wv;
+    const int hh = (int)(r % H); r /= H;
+    const int dd = (int)(r % D); r /= D;
+    const int vol = (int)r;  // b*M + m
+    const int b = vol / M, m = vol - b * M;
+    const int w0 = wv * VEC;
+    const int w = w0 / wp, p3 = w0 - w * wp;
+    const int h = hh / hp, p2 = hh - h * hp;
+    const int d = dd / dp, p1 = dd - d * dp;
+    const int t = (h * Wn + w) * Dn + d;
+    const int f = (p1 * hp + p2) * wp + p3;
+    bf16* dst = out + ((int64_t)(m * B + b) * P + t) * pd + f;
+    const T* src = img + idx * VEC;
+    if constexpr (VEC == 8) {
+      bf16x8 o;
+      if constexpr (sizeof(T) == 4) {
+        const f32x4 a = ((const f32x4*)src)[0], c = ((const f32x4*)src)[1];
+        o = bf16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(c[0]), f2bf(c[1]), f2bf(c[2]), f2bf(c[3])};
+      } else {
+        o = *(const bf16x8*)src;
+      }
+      *(bf16x8*)dst = o;
+    } else {
+      *dst = f2bf((float)*src);
+    }
+  }
+}
+
+__global__ void cls_row_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x, int MB, int64_t row_stride, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < MB * d) {
+    const int c = i % d, mb = i / d;
+    x[(int64_t)mb * row_stride + c] = cls[c] + pos[c];
+  }
+}
+
+// dpos[n, c] += sum_mb dx[mb, n, c];  dcls[c] += sum_mb dx[mb, 0, c]
+__global__ void embed_bwd_kernel(const float* __restrict__ dx, float* __restrict__ dpos, float* __restrict__ dcls, int MB, int N, int d) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // over N*d/4
+  const int dv = d >> 2;
+  if (i >= (int64_t)N * dv) return;
+  const int n = (int)(i / dv), c = (int)(i - (int64_t)n * dv) * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int mb = 0; mb < MB; ++mb) acc += *(const f32x4*)(dx + ((int64_t)mb * N + n) * d + c);
+  f32x4* dp = (f32x4*)(dpos + (int64_t)n * d + c);
+  *dp += acc;
+  if (n == 0) *(f32x4*)(dcls + c) += acc;
+}
+
+__global__ void cast_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t n) {
+  const int64_t nv = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 a = ((const f32x4*)src)[2 * i], c = ((const f32x4*)src)[2 * i + 1];
+    ((bf16x8*)dst)[i] = bf16x8{f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(c[0]), f2bf(c[1]), f2bf(c[2]), f2bf(c[3])};
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nv << 3) + threadIdx.x] = f2bf(src[(nv << 3) + threadIdx.x]);
+}
+
+// column sums: block = 64 column-quads (256 columns) x 4 row lanes; rows strided by gridDim.y*4
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out, int rows, int n) {
+  __shared__ f32x4 red[4][64];
+  const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + cq) * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (col < n) {
+    for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) {
+      if constexpr (sizeof(T) == 4) {
+        acc += *(const f32x4*)(x + (int64_t)r * ldx + col);
+      } else {
+        const bf16x4 v = *(const bf16x4*)(x + (int64_t)r * ldx + col);
+        acc += f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+      }
+    }
+  }
+  red[rl][cq] = acc;
+  __syncthreads();
+  if (rl == 0 && col < n) {
+    acc = red[0][cq] + red[1][cq] + red[2][cq] + red[3][cq];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out + col + e, acc[e]);
+  }
+}
+
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, float inv_keep, uint64_t seed) {
+  const uint32_t thr = (uint32_t)(p * 16777216.0f);  // drop when the 24-bit hash < p * 2^24
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const bool keep = (hash32(seed, (uint64_t)i) & 0xFFFFFFu) >= thr;
+    y[i] = keep ? (T)((float)x[i] * inv_keep) : (T)0.0f;
+  }
+}
+
+// ---- tiny fp32 linear (num_classes head) ---------------------------------------------------
+__global__ void small_linear_fwd_kernel(const bf16* __restrict__ x, int64_t ldx, const float* __restrict__ W, const float* __restrict__ b,
+                                        float* __restrict__ y, int M, int N, int K) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= M * N) return;
+  const int m = wave / N, n = wave - m * N;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc = fmaf(bf2f(x[(int64_t)m * ldx + k]), W[(int64_t)n * K + k], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) y[wave] = acc + (b ? b[n] : 0.f);
+}
+
+__global__ void small_linear_bwd_kernel(const float* __restrict__ dy, const bf16* __restrict__ x, int64_t ldx, const float* __restrict__ W,
+                                        bf16* __restrict__ dx, int64_t lddx, float* __restrict__ dW, float* __restrict__ db, int M, int N, int K) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < K) {
+    for (int m = 0; m < M; ++m) {
+      float acc = 0.f;
+      for (int n = 0; n < N; ++n) acc = fmaf(dy[m * N + n], W[(int64_t)n * K + k], acc);
+      dx[(int64_t)m * lddx + k] = f2bf(acc);
+    }
+    for (int n = 0; n < N; ++n) {
+      float acc = 0.f;
+      for (int m = 0; m < M; ++m) acc = fmaf(dy[m * N + n], bf2f(x[(int64_t)m * ldx + k]), acc);
+      dW[(int64_t)n * K + k] += acc;
+    }
+  }
+  if (k < N) {
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc += dy[m * N + k];
+    db[k] += acc;
+  }
+}
+
+// logits = mean_m logits_m; loss = mean_b CE(logits_b, label_b) with label smoothing;
+// dlogits_m = (softmax - target) / (B * M).   One block; B*C small.
+__global__ void mean_ce_kernel(const float* __restrict__ logits_m, const int64_t* __restrict__ labels, float eps, float* __restrict__ logits,
+                               float* __restrict__ loss, float* __restrict__ dlogits_m, int M, int B, int C) {
+  __shared__ float red[4];
+  float part = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) {
+      float s = 0.f;
+      for (int m = 0; m < M; ++m) s += logits_m[((int64_t)m * B + b) * C + c];
+      s /= (float)M;
+      logits[b * C + c] = s;
+      mx = fmaxf(mx, s);
+    }
+    float z = 0.f;
+    for (int c = 0; c < C; ++c) z += expf(logits[b * C + c] - mx);
+    const float lz = mx + logf(z);
+    const int y = (int)labels[b];
+    float l = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float logp = logits[b * C + c] - lz;
+      const float tgt = (c == y ? 1.0f - eps : 0.f) + eps / (float)C;
+      l -= tgt * logp;
+      const float g = (expf(logp) - tgt) / (float)(B * M);
+      for (int m = 0; m < M; ++m) dlogits_m[((int64_t)m * B + b) * C + c] = g;
+    }
+    part += l;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    *loss = t / (float)B;
+  }
+}
+
+}  // namespace xvit
+
+using namespace xvit;
+
+static int grid_for(int64_t work, int block) {
+  int64_t g = (work + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+extern "C" int xvit_patchify(const void* img, int img_dtype, void* out, int B, int M, int D, int H, int W, int dp, int hp, int wp,
+                             xvit_stream_t stream) {
+  XVIT_REQUIRE(img && out, "xvit_patchify: null pointer");
+  XVIT_REQUIRE(B > 0 && M > 0 && D > 0 && H > 0 && W > 0 && dp > 0 && hp > 0 && wp > 0, "xvit_patchify: bad sizes");
+  XVIT_REQUIRE(D % dp == 0 && H % hp == 0 && W % wp == 0, "xvit_patchify: image dimensions must be divisible by the patch size");
+  XVIT_REQUIRE(img_dtype == XVIT_F32 || img_dtype == XVIT_BF16, "xvit_patchify: bad dtype");
+  const int64_t total = (int64_t)B * M * D * H * W;
+  hipStream_t s = (hipStream_t)stream;
+  const bool vec = (wp % 8 == 0) && ((reinterpret_cast<uintptr_t>(img) & 31) == 0);
+  bf16* o = (bf16*)out;
+  if (vec) {
+    const int64_t tv = total / 8;
+    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, tv);
+    else hipLaunchKernelGGL((patchify_kernel<bf16, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, tv);
+  } else {
+    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, total);
+    else hipLaunchKernelGGL((patchify_kernel<bf16, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, total);
+  }
+  return check_launch("xvit_patchify");
+}
+
+extern "C" int xvit_cls_row_fwd(const float* cls, const float* pos, float* x, int MB, int N, int d, xvit_stream_t stream) {
+  XVIT_REQUIRE(cls && pos && x && MB > 0 && N > 0 && d > 0, "xvit_cls_row_fwd: bad arguments");
+  hipLaunchKernelGGL(cls_row_kernel, dim3((MB * d + 255) / 256), dim3(256), 0, (hipStream_t)stream, cls, pos, x, MB, (int64_t)N * d, d);
+  return check_launch("xvit_cls_row_fwd");
+}
+
+extern "C" int xvit_embed_bwd(const float* dx, float* dpos, float* dcls, int MB, int N, int d, xvit_stream_t stream) {
+  XVIT_REQUIRE(dx && dpos && dcls && MB > 0 && N > 0 && d > 0 && d % 4 == 0, "xvit_embed_bwd: bad arguments");
+  const int64_t work = (int64_t)N * (d / 4);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dx, dpos, dcls, MB, N, d);
+  return check_launch("xvit_embed_bwd");
+}
+
+extern "C" int xvit_cast_f32_bf16(const float* src, void* dst, int64_t n, xvit_stream_t stream) {
+  XVIT_REQUIRE(src && dst && n > 0, "xvit_cast_f32_bf16: bad arguments");
+  XVIT_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0, "xvit_cast_f32_bf16: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n);
+  return check_launch("xvit_cast_f32_bf16");
+}
+
+extern "C" int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, int n, int accumulate, xvit_stream_t stream) {
+  XVIT_REQUIRE(x && out && rows > 0 && n > 0, "xvit_colsum: bad arguments");
+  XVIT_REQUIRE(n % 4 == 0 && ldx % 4 == 0, "xvit_colsum: n and ldx must be multiples of 4");
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) {
+    const hipError_t e = hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s);
+    if (e != hipSuccess) { set_error("xvit_colsum: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+  }
+  int gy = (rows + 255) / 256;
+  if (gy > 64) gy = 64;
+  const dim3 grid((n / 4 + 63) / 64, gy), block(256);
+  if (x_dtype == XVIT_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, ldx, out, rows, n);
+  else hipLaunchKernelGGL((colsum_kernel<bf16>), grid, block, 0, s, (const bf16*)x, ldx, out, rows, n);
+  return check_launch("xvit_colsum");
+}
+
+extern "C" int xvit_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, xvit_stream_t stream) {
+  XVIT_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "xvit_dropout: bad arguments");
+  const float inv = 1.0f / (1.0f - p);
+  if (dtype == XVIT_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, p, inv, seed);
+  else hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n, p, inv, seed);
+  return check_launch("xvit_dropout");
+}
+
+extern "C" int xvit_small_linear_fwd(const void* x, int64_t ldx, const float* W, const float* b, float* y, int M, int N, int K, xvit_stream_t stream) {
+  XVIT_REQUIRE(x && W && y && M > 0 && N > 0 && K > 0, "xvit_small_linear_fwd: bad arguments");
+  const int waves = M * N;
+  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, W, b, y, M, N, K);
+  return check_launch("xvit_small_linear_fwd");
+}
+
+extern "C" int xvit_small_linear_bwd(const float* dy, const void* x, int64_t ldx, const float* W, void* dx, int64_t lddx, float* dW, float* db, int M,
+                                     int N, int K, xvit_stream_t stream) {
+  XVIT_REQUIRE(dy && x && W && dx && dW && db && M > 0 && N > 0 && K >= N, "xvit_small_linear_bwd: bad arguments");
+  hipLaunchKernelGGL(small_linear_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, (const bf16*)x, ldx, W, (bf16*)dx, lddx, dW, db, M,
+                     N, K);
+  return check_launch("xvit_small_linear_bwd");
+}
+
+extern "C" int xvit_mean_ce(const float* logits_m, const int64_t* labels, float label_smoothing, float* logits, float* loss, float* dlogits_m, int M,
+                            int B, int C, xvit_stream_t stream) {
+  XVIT_REQUIRE(logits_m && labels && logits && loss && dlogits_m && M > 0 && B > 0 && C > 0, "xvit_mean_ce: bad arguments");
+  hipLaunchKernelGGL(mean_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_m, labels, label_smoothing, logits, loss, dlogits_m, M, B, C);
+  return check_launch("xvit_mean_ce");
+}

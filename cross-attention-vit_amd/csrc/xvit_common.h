@@ -1,0 +1,91 @@
+// Shared device/host helpers for the xvit gfx950 kernels.  CDNA4 only: wave64, MFMA,
+// buffer_load ... lds (LDS-DMA), ds_read_b64_tr_b16.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/xvit.h"
+
+namespace xvit {
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define XVIT_LDS __attribute__((address_space(3)))
+
+constexpr int kWave = 64;
+
+// ---- error plumbing (host) -----------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define XVIT_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      ::xvit::set_error(__VA_ARGS__);      \
+      return XVIT_ERR_ARG;                 \
+    }                                      \
+  } while (0)
+
+// ---- device helpers ------------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }  // v_cvt_pk_bf16_f32, RNE, NaN-safe
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// Wave-uniform value made provably uniform for the compiler (SGPR).
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Buffer resource over [base, base+bytes): out-of-range loads return 0, stores are dropped.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ uint32_t clamp_bytes(int64_t b) {
+  return b <= 0 ? 0u : (b > 0x7FFFFFFFll ? 0x7FFFFFFFu : (uint32_t)b);
+}
+
+// 16-byte LDS-DMA: LDS[lds_base + lane*16 .. +16) <- buffer[voff + soff .. +16)
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, XVIT_LDS void* lds_base, uint32_t voff, uint32_t soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_base, 16, voff, soff, 0, 0);
+}
+
+__device__ __forceinline__ s16x4 lds_read_tr16(const XVIT_LDS void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((XVIT_LDS s16x4*)p);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// exact (erf) GELU and its derivative, fp32
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// counter-based RNG for dropout: one 32-bit hash per element index (same mask in fwd and bwd)
+__device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
+
+}  // namespace xvit

@@ -1,0 +1,70 @@
+"""ctypes binding of libxvit_hip.so (the C ABI declared in include/xvit.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxvit_hip.so")
+
+i32, i64, f32, u64, vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    """struct xvit_gemm_args (include/xvit.h)."""
+    _fields_ = [(n, i32) for n in (
+        "layout", "M", "N", "K", "batch", "c_dtype", "act", "accumulate", "split_k",
+        "res_row_mod", "res_row_off", "out_seg_rows", "out_seg_skip", "out_row_off", "reserved")] + [
+        (n, vp) for n in ("A", "B", "C", "bias", "residual", "aux")] + [
+        (n, i64) for n in ("lda", "ldb", "ldc", "ldr", "ldaux",
+                           "stride_a", "stride_b", "stride_c", "stride_bias", "stride_r", "stride_aux")]
+
+
+# name -> argtypes; every function returns int except the two noted below
+SIGNATURES = {
+    "xvit_gemm": [C.POINTER(GemmArgs), vp],
+    "xvit_small_linear_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
+    "xvit_small_linear_bwd": [vp, vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, vp],
+    "xvit_layernorm_fwd": [vp, vp, i64, i32, vp, vp, f32, vp, i64, vp, vp, i32, i32, vp],
+    "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, vp],
+    "xvit_attn_fwd": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, vp],
+    "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "xvit_cls_xattn_fwd": [vp, i64, vp, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp],
+    "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, f32, vp],
+    "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "xvit_cls_row_fwd": [vp, vp, vp, i32, i32, i32, vp],
+    "xvit_embed_bwd": [vp, vp, vp, i32, i32, i32, vp],
+    "xvit_cast_f32_bf16": [vp, vp, i64, vp],
+    "xvit_colsum": [vp, i32, i64, vp, i32, i32, i32, vp],
+    "xvit_dropout": [vp, vp, i32, i64, f32, u64, vp],
+    "xvit_mean_ce": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp],
+}
+EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string"])
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"xvit: {LIB_PATH} is missing. Build it with `python cross-attention-vit_amd/build.py` "
+                "(hipcc, gfx950). There is no CPU or PyTorch fallback for this path.")
+        lib = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        lib.xvit_version.restype = C.c_int
+        lib.xvit_last_error_string.restype = C.c_char_p
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().xvit_last_error_string().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")

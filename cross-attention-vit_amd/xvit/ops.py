@@ -1,0 +1,233 @@
+"""Thin tensor-level wrappers over the C ABI: pointer/stride extraction, current-stream
+plumbing, loud failure.  No autograd here (see functional.py) and no fallback: a tensor that
+is not on the GPU is an error."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmArgs
+
+BF16, F32 = 0, 1
+NT, NN, TN = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t) -> int | None:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("xvit: tensor is not on the GPU; the HIP path has no CPU fallback")
+    return t.data_ptr()
+
+
+def _dt(t) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"xvit: unsupported dtype {t.dtype}")
+
+
+def _rows2d(t):
+    """Leading dimension of a 2-D row-major view."""
+    assert t.dim() == 2 and t.stride(1) == 1, f"need a row-major 2-D tensor, got shape {tuple(t.shape)} strides {t.stride()}"
+    return t.stride(0)
+
+
+def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NONE, accumulate=False,
+         split_k=1, res_row_mod=0, res_row_off=0, out_seg=(0, 0, 0), M=None, N=None, K=None):
+    """C = op(A) op(B) with the fused epilogue of include/xvit.h.  2-D tensors, or 3-D
+    [batch, rows, cols] for a strided batch (all of A, B, C and optional bias 2-D / residual /
+    aux 3-D then carry the batch in dim 0)."""
+    a = GemmArgs()
+    batched = A.dim() == 3
+    A2, B2, C2 = (A[0], B[0], C_out[0]) if batched else (A, B, C_out)
+    if layout == NT:
+        m, k = A2.shape; n = B2.shape[0]; assert B2.shape[1] == k
+    elif layout == NN:
+        m, k = A2.shape; n = B2.shape[1]; assert B2.shape[0] == k
+    else:
+        k, m = A2.shape; n = B2.shape[1]; assert B2.shape[0] == k
+    a.layout, a.M, a.N, a.K = layout, M or m, N or n, K or k
+    a.batch = A.shape[0] if batched else 1
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
+    a.c_dtype, a.act, a.accumulate, a.split_k = _dt(C_out), act, int(bool(accumulate)), split_k
+    a.res_row_mod, a.res_row_off = res_row_mod, res_row_off
+    a.out_seg_rows, a.out_seg_skip, a.out_row_off = out_seg
+    a.A, a.B, a.C = _ptr(A), _ptr(B), _ptr(C_out)
+    a.lda, a.ldb, a.ldc = _rows2d(A2), _rows2d(B2), _rows2d(C2)
+    if batched:
+        a.stride_a, a.stride_b, a.stride_c = A.stride(0), B.stride(0), C_out.stride(0)
+    if bias is not None:
+        assert bias.dtype == torch.float32
+        a.bias = _ptr(bias)
+        if batched:
+            a.stride_bias = bias.stride(0)
+    if residual is not None:
+        assert residual.dtype == torch.float32
+        r2 = residual[0] if batched else residual
+        a.residual, a.ldr = _ptr(residual), _rows2d(r2)
+        if batched:
+            a.stride_r = residual.stride(0)
+    if aux is not None:
+        assert aux.dtype == torch.bfloat16
+        x2 = aux[0] if batched else aux
+        a.aux, a.ldaux = _ptr(aux), _rows2d(x2)
+        if batched:
+            a.stride_aux = aux.stride(0)
+    _lib.check(_lib.load().xvit_gemm(C.byref(a), _stream()), "xvit_gemm")
+    return C_out
+
+
+def layernorm_fwd(x, gamma, beta, eps, *, x_alt=None, seq_len=0, out=None):
+    """x fp32 [rows, d] (row stride free) -> (y bf16 [rows, d], mean, rstd)."""
+    rows, d = x.shape
+    y = out if out is not None else torch.empty(rows, d, dtype=torch.bfloat16, device=x.device)
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    if x_alt is not None:
+        assert x_alt.shape == x.shape and x_alt.stride() == x.stride()
+    _lib.check(_lib.load().xvit_layernorm_fwd(_ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(gamma), _ptr(beta), eps,
+                                              _ptr(y), _rows2d(y), _ptr(mean), _ptr(rstd), rows, d, _stream()), "xvit_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, x_alt=None, seq_len=0, dres=None, want_bf16=False):
+    """-> (dx fp32, dx_bf16 | None); dgamma/dbeta (fp32, [d]) are accumulated into."""
+    rows, d = x.shape
+    dx = torch.empty(rows, d, dtype=torch.float32, device=x.device)
+    dxb = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    _lib.check(_lib.load().xvit_layernorm_bwd(
+        _ptr(dy), _rows2d(dy), _ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(mean), _ptr(rstd), _ptr(gamma),
+        _ptr(dres), _rows2d(dres) if dres is not None else 0, _ptr(dx), d, _ptr(dxb), d,
+        _ptr(dgamma), _ptr(dbeta), rows, d, _stream()), "xvit_layernorm_bwd")
+    return dx, dxb
+
+
+def attn_fwd(qkv, B, N, H, scale):
+    """qkv bf16 [B*N, 3d] (q | k | v along columns) -> (o bf16 [B*N, d], lse fp32 [B, H, N])."""
+    d = qkv.shape[1] // 3
+    dh = d // H
+    o = torch.empty(B * N, d, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    ld = _rows2d(qkv)
+    p = qkv.data_ptr()
+    _lib.check(_lib.load().xvit_attn_fwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), N * d, d, _ptr(lse), B, H, N, dh, scale, _stream()),
+               "xvit_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(qkv, o, d_o, lse, B, N, H, scale):
+    """-> dqkv bf16 [B*N, 3d]."""
+    d = qkv.shape[1] // 3
+    dh = d // H
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    ld = _rows2d(qkv)
+    assert dqkv.stride(0) == ld and _rows2d(o) == d and _rows2d(d_o) == d
+    p, g = qkv.data_ptr(), dqkv.data_ptr()
+    _lib.check(_lib.load().xvit_attn_bwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), _ptr(d_o), N * d, d, _ptr(lse), _ptr(delta),
+                                         g, g + 2 * d, g + 4 * d, B, H, N, dh, scale, _stream()), "xvit_attn_bwd")
+    return dqkv
+
+
+def cls_xattn_fwd(q, kv, B, N, H, scale):
+    """q bf16 [B, d]; kv bf16 [B*N, 2d] (k | v) -> (o bf16 [B, d], p fp32 [B, H, N])."""
+    d = q.shape[1]
+    o = torch.empty(B, d, dtype=torch.bfloat16, device=q.device)
+    p = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
+    ld = _rows2d(kv)
+    kp = kv.data_ptr()
+    _lib.check(_lib.load().xvit_cls_xattn_fwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(o), d, _ptr(p), B, H, N, d // H, scale, _stream()),
+               "xvit_cls_xattn_fwd")
+    return o, p
+
+
+def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale):
+    """-> (dq fp32 [B, d], dkv bf16 [B*N, 2d])."""
+    d = q.shape[1]
+    dq = torch.empty(B, d, dtype=torch.float32, device=q.device)
+    dkv = torch.empty_like(kv)
+    ld = _rows2d(kv)
+    assert dkv.stride(0) == ld
+    kp, gp = kv.data_ptr(), dkv.data_ptr()
+    _lib.check(_lib.load().xvit_cls_xattn_bwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(p), _ptr(d_o), _rows2d(d_o), _ptr(dq), d,
+                                              gp, gp + 2 * d, B, H, N, d // H, scale, _stream()), "xvit_cls_xattn_bwd")
+    return dq, dkv
+
+
+def patchify(img, patch):
+    """img [B, M, 1, D, H, W] fp32|bf16 contiguous -> patches bf16 [M, B*P, pd]."""
+    assert img.dim() == 6 and img.shape[2] == 1 and img.is_contiguous()
+    B, M, _, D, H, W = img.shape
+    dp, hp, wp = patch
+    P, pd = (D // dp) * (H // hp) * (W // wp), dp * hp * wp
+    out = torch.empty(M, B * P, pd, dtype=torch.bfloat16, device=img.device)
+    _lib.check(_lib.load().xvit_patchify(_ptr(img), _dt(img), _ptr(out), B, M, D, H, W, dp, hp, wp, _stream()), "xvit_patchify")
+    return out
+
+
+def cls_row_fwd(cls, pos, x, MB, N, d):
+    _lib.check(_lib.load().xvit_cls_row_fwd(_ptr(cls), _ptr(pos), _ptr(x), MB, N, d, _stream()), "xvit_cls_row_fwd")
+
+
+def embed_bwd(dx, dpos, dcls, MB, N, d):
+    _lib.check(_lib.load().xvit_embed_bwd(_ptr(dx), _ptr(dpos), _ptr(dcls), MB, N, d, _stream()), "xvit_embed_bwd")
+
+
+def cast_bf16(src, out=None):
+    """fp32 -> bf16 (contiguous)."""
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    out = out if out is not None else torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+    assert out.is_contiguous() and out.numel() == src.numel()
+    _lib.check(_lib.load().xvit_cast_f32_bf16(_ptr(src), _ptr(out), src.numel(), _stream()), "xvit_cast_f32_bf16")
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    rows, n = x.shape
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+        accumulate = False
+    _lib.check(_lib.load().xvit_colsum(_ptr(x), _dt(x), _rows2d(x), _ptr(out), rows, n, int(accumulate), _stream()), "xvit_colsum")
+    return out
+
+
+def dropout(x, p, seed, out=None):
+    assert x.is_contiguous()
+    out = out if out is not None else torch.empty_like(x)
+    _lib.check(_lib.load().xvit_dropout(_ptr(x), _ptr(out), _dt(x), x.numel(), p, seed, _stream()), "xvit_dropout")
+    return out
+
+
+def small_linear_fwd(x, W, b):
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().xvit_small_linear_fwd(_ptr(x), _rows2d(x), _ptr(W), _ptr(b), _ptr(y), M, N, K, _stream()), "xvit_small_linear_fwd")
+    return y
+
+
+def small_linear_bwd(dy, x, W, dW, db):
+    M, K = x.shape
+    N = W.shape[0]
+    dx = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().xvit_small_linear_bwd(_ptr(dy), _ptr(x), _rows2d(x), _ptr(W), _ptr(dx), K, _ptr(dW), _ptr(db), M, N, K, _stream()),
+               "xvit_small_linear_bwd")
+    return dx
+
+
+def mean_ce(logits_m, labels, smoothing):
+    M, B, Cn = logits_m.shape
+    logits = torch.empty(B, Cn, dtype=torch.float32, device=logits_m.device)
+    loss = torch.empty((), dtype=torch.float32, device=logits_m.device)
+    dl = torch.empty_like(logits_m)
+    _lib.check(_lib.load().xvit_mean_ce(_ptr(logits_m), _ptr(labels), smoothing, _ptr(logits), _ptr(loss), _ptr(dl), M, B, Cn, _stream()), "xvit_mean_ce")
+    return logits, loss, dl

@@ -1,0 +1,152 @@
+/* xvit.h — C ABI of libxvit_hip.so: the MI355X (gfx950) hot path of the cross-attention 3-D ViT.
+ *
+ * The reference (vsahni3/cross-attention-ViT) has no FFI; its hot path sits behind plain
+ * torch.nn.Module calls.  Each entry point below stands in for the eager-PyTorch op sequence
+ * of the reference lines it cites (paths relative to the reference repo).  The Python host
+ * side (cross-attention-vit_amd/xvit/) binds these with ctypes and re-exposes the reference's
+ * own nn.Module signatures; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions (SURVEY.md §8(b), C-ABI face)
+ *   - extern "C", raw device pointers + explicit sizes/strides (in ELEMENTS) + a HIP stream
+ *     handle passed as void*.  No torch types cross this boundary.
+ *   - The caller allocates every output and workspace; the library never allocates, frees or
+ *     keeps a pointer after the call returns.  Every launch is enqueued on `stream`; there is
+ *     no internal synchronisation, so all entry points are HIP-graph capturable.
+ *   - Return: 0 = OK; <0 = argument/shape/unsupported error (nothing launched; text via
+ *     xvit_last_error_string()); >0 = hipError_t reported by the launch.
+ *   - Activations are bf16 (fp32 accumulate); the residual stream, LayerNorm statistics,
+ *     parameter gradients and the loss are fp32.
+ */
+#ifndef XVIT_H
+#define XVIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XVIT_VERSION 100 /* 0.1.0 */
+
+enum { XVIT_OK = 0, XVIT_ERR_ARG = -1, XVIT_ERR_UNSUPPORTED = -2 };
+enum { XVIT_BF16 = 0, XVIT_F32 = 1 };
+
+typedef void* xvit_stream_t; /* hipStream_t */
+
+int xvit_version(void);
+const char* xvit_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue.  Replaces every nn.Linear on the path and its autograd backward:
+ *   model_cross.py:23,26 (FeedForward), :43,46 (to_qkv / to_out), :81-85 (wq/wk/wv/proj),
+ *   :168 (patch_to_embedding), :177-181 (mlp_head); model.py:110-111,133-137.
+ * C[M,N] = op(A) * op(B), bf16 operands, fp32 accumulate (v_mfma_f32_16x16x32_bf16).
+ *   layout NT: A[M,K] (k contiguous), B[N,K] (k contiguous)       y = x W^T      (forward)
+ *   layout NN: A[M,K] (k contiguous), B[K,N] (n contiguous)       dx = dy W      (dgrad)
+ *   layout TN: A stored [K,M] (m contiguous), B[K,N] (n contig.)  dW = dy^T x    (wgrad)
+ * Epilogue, in this order: +bias[n]; act; +residual; row remap; store / accumulate.
+ * ---------------------------------------------------------------------------------------- */
+enum { XVIT_GEMM_NT = 0, XVIT_GEMM_NN = 1, XVIT_GEMM_TN = 2 };
+enum { XVIT_ACT_NONE = 0,
+       XVIT_ACT_GELU = 1,  /* aux (bf16, optional) receives the pre-activation z; C = gelu(z), erf form */
+       XVIT_ACT_DGELU = 2  /* aux (bf16) supplies z; C = acc * gelu'(z) */ };
+enum { XVIT_ACC_STORE = 0, XVIT_ACC_ADD = 1 /* fp32 C only: C += result */ };
+
+typedef struct xvit_gemm_args {
+  int32_t layout, M, N, K, batch;
+  int32_t c_dtype;    /* XVIT_BF16 | XVIT_F32 */
+  int32_t act;        /* XVIT_ACT_* */
+  int32_t accumulate; /* XVIT_ACC_* */
+  int32_t split_k;    /* >=1.  >1: fp32 C, partial sums added atomically (C must hold the value to add to) */
+  /* residual row = res_row_off + (row % res_row_mod) when res_row_mod > 0 (broadcast, e.g. pos_embedding) */
+  int32_t res_row_mod, res_row_off;
+  /* output row = row + (row / out_seg_rows) * out_seg_skip + out_row_off when out_seg_rows > 0
+     (patch rows -> token rows that leave room for the CLS row, model_cross.py:195-196) */
+  int32_t out_seg_rows, out_seg_skip, out_row_off;
+  int32_t reserved;
+  const void* A; const void* B; void* C;
+  const float* bias;     /* [N] fp32 or NULL */
+  const float* residual; /* fp32 [*, N] or NULL */
+  void* aux;             /* bf16 [M, N] or NULL (see act) */
+  int64_t lda, ldb, ldc, ldr, ldaux;                                  /* leading dims, elements */
+  int64_t stride_a, stride_b, stride_c, stride_bias, stride_r, stride_aux; /* per-batch strides */
+} xvit_gemm_args;
+
+int xvit_gemm(const xvit_gemm_args* args, xvit_stream_t stream);
+
+/* Tiny fp32 linear for shapes the MFMA tile cannot address (the num_classes=2 head,
+ * model_cross.py:181).  y[M,N] = x[M,K] W[N,K]^T + b.  x is bf16, W/b/y fp32.  */
+int xvit_small_linear_fwd(const void* x_bf16, int64_t ldx, const float* W, const float* b, float* y, int M, int N, int K, xvit_stream_t stream);
+/* dx[M,K] (bf16) = dy W;  dW[N,K] += dy^T x;  db[N] += colsum(dy).  dy fp32. */
+int xvit_small_linear_bwd(const float* dy, const void* x_bf16, int64_t ldx, const float* W, void* dx_bf16, int64_t lddx,
+                          float* dW, float* db, int M, int N, int K, xvit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm (model_cross.py:11-17 PreNorm, :174/:203 final norm; model.py:186-187,207 eps=1e-6).
+ * x is the fp32 residual stream [rows, d] (row stride ldx).  If x_alt != NULL, rows with
+ * (row % seq_len) == 0 are read from x_alt at the same offset: the "cls of i + patches of j"
+ * concatenation of model_cross.py:140 without materialising it.
+ * ---------------------------------------------------------------------------------------- */
+int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_len, const float* gamma, const float* beta,
+                       float eps, void* y_bf16, int64_t ldy, float* mean, float* rstd, int rows, int d, xvit_stream_t stream);
+/* dx = (dres ? dres : 0) + LN'(dy); also emits a bf16 copy of dx (the next GEMMs' operand) when
+ * dx_bf16 != NULL; dgamma/dbeta are ADDED (fp32 atomics). */
+int xvit_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len,
+                       const float* mean, const float* rstd, const float* gamma, const float* dres, int64_t lddres,
+                       float* dx, int64_t lddx, void* dx_bf16, int64_t lddxb, float* dgamma, float* dbeta, int rows, int d,
+                       xvit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused self-attention (model_cross.py:53-60; model.py:165-172): softmax(q k^T * scale) v
+ * without materialising the [B,H,N,N] scores.  Element (b, n, h, :) of q/k/v lives at
+ * ptr + b*stride_b + n*stride_n + h*dh (q, k, v normally point into one [B,N,3d] tensor).
+ * dh must be 64.  lse[B,H,N] = log-sum-exp of the scaled scores (saved for backward).
+ * ---------------------------------------------------------------------------------------- */
+int xvit_attn_fwd(const void* q, const void* k, const void* v, int64_t stride_b, int64_t stride_n, void* o, int64_t o_stride_b,
+                  int64_t o_stride_n, float* lse, int B, int H, int N, int dh, float scale, xvit_stream_t stream);
+/* delta[B,H,N] is caller-provided fp32 workspace (rowsum(do*o)).  dq/dk/dv use the q/k/v strides. */
+int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t stride_b, int64_t stride_n, const void* o, const void* d_o,
+                  int64_t o_stride_b, int64_t o_stride_n, const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H,
+                  int N, int dh, float scale, xvit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CLS-query cross-attention (model_cross.py:91-99): one query row per (b, h) against N keys.
+ * q [B, d] bf16 (row stride ldq); k/v as above; o [B, d] bf16; p [B,H,N] fp32 probabilities
+ * (saved for backward).  HBM-bound GEMV-style kernel.
+ * ---------------------------------------------------------------------------------------- */
+int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t stride_b, int64_t stride_n, void* o,
+                       int64_t ldo, float* p, int B, int H, int N, int dh, float scale, xvit_stream_t stream);
+int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t stride_b, int64_t stride_n, const float* p,
+                       const void* d_o, int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, int B, int H, int N, int dh,
+                       float scale, xvit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * 3-D patchify (model_cross.py:193): img [B, M, 1, D, H, W] (fp32 or bf16, contiguous) ->
+ * patches bf16 [M, B, P, pd]; token t = (h*Wn + w)*Dn + d, feature f = (p1*hp + p2)*wp + p3.
+ * ---------------------------------------------------------------------------------------- */
+int xvit_patchify(const void* img, int img_dtype, void* patches_bf16, int B, int M, int D, int H, int W, int dp, int hp, int wp,
+                  xvit_stream_t stream);
+/* x[m, b, 0, :] = cls + pos[0]  (model_cross.py:195-197, the CLS row); x fp32 [M*B, N, d] */
+int xvit_cls_row_fwd(const float* cls, const float* pos, float* x, int MB, int N, int d, xvit_stream_t stream);
+/* dpos[n,:] += sum_{mb} dx[mb,n,:];  dcls += sum_{mb} dx[mb,0,:] */
+int xvit_embed_bwd(const float* dx, float* dpos, float* dcls, int MB, int N, int d, xvit_stream_t stream);
+
+/* ---- elementwise / reductions --------------------------------------------------------- */
+int xvit_cast_f32_bf16(const float* src, void* dst_bf16, int64_t n, xvit_stream_t stream);
+/* out[n] (+)= sum_r x[r, n];  x bf16 or fp32 */
+int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, int n, int accumulate, xvit_stream_t stream);
+/* dropout with a counter-based mask (same (seed, element index) -> same mask in fwd and bwd):
+ * y = x * keep / (1-p).  In-place allowed.  dtype XVIT_BF16 | XVIT_F32. */
+int xvit_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, xvit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Head tail (model_cross.py:205-211): logits = mean_m logits_m;  loss = CE(logits, labels,
+ * label_smoothing), mean over the batch.  Also writes dlogits_m[M,B,C] = d loss / d logits_m.
+ * ---------------------------------------------------------------------------------------- */
+int xvit_mean_ce(const float* logits_m, const int64_t* labels, float label_smoothing, float* logits, float* loss, float* dlogits_m,
+                 int M, int B, int C, xvit_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XVIT_H */

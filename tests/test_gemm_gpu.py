@@ -1,0 +1,130 @@
+"""GPU parity: xvit_gemm (all layouts + epilogues) against fp32 matmul on the same bf16 operands."""
+import math
+
+import pytest
+import torch
+
+from _util import assert_close, dev, randn, rt
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from xvit import ops
+    return ops
+
+
+def _gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+def _dgelu(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+SHAPES = [(64, 128, 64), (200, 192, 128), (1026, 768, 768), (130, 576, 192), (513, 2304, 768), (33, 3072, 768), (2, 768, 768)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+@pytest.mark.parametrize("out_f32", [False, True])
+def test_nt(M, N, K, out_f32):
+    ops = _ops()
+    a, w = rt(randn(M, K, seed=1)), rt(randn(N, K, seed=2, scale=K ** -0.5))
+    C = torch.full((M, N), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dev())
+    ops.gemm(ops.NT, a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C)
+    assert_close(C, a @ w.T, f"NT {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 192, 128), (1026, 768, 3072), (513, 768, 2304), (17, 192, 576)])
+def test_nn_dgrad(M, N, K):
+    """dx[M,N] = dy[M,K] @ W[K,N]  (W stored [out=K, in=N], n contiguous)."""
+    ops = _ops()
+    dy, w = rt(randn(M, K, seed=3)), rt(randn(K, N, seed=4, scale=K ** -0.5))
+    C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.gemm(ops.NN, dy.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C)
+    assert_close(C, dy @ w, f"NN {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K,split", [(192, 128, 200, 1), (768, 768, 1026, 1), (768, 3072, 1026, 3), (2304, 768, 513, 2),
+                                         (576, 192, 34, 1), (768, 768, 4104, 8), (128, 4096, 1024, 2)])
+def test_tn_wgrad(M, N, K, split):
+    """dW[M,N] = dy[K,M]^T @ x[K,N]: the contraction (tokens) is the row index of both operands and
+    need not be a multiple of anything (zero-filled by the DMA)."""
+    ops = _ops()
+    dy, x = rt(randn(K, M, seed=5)), rt(randn(K, N, seed=6))
+    C = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    ops.gemm(ops.TN, dy.to(dev(), torch.bfloat16), x.to(dev(), torch.bfloat16), C, split_k=split)
+    assert_close(C, dy.T @ x, f"TN {M}x{N}x{K} split{split}")
+    # accumulate on top (beta = 1)
+    ops.gemm(ops.TN, dy.to(dev(), torch.bfloat16), x.to(dev(), torch.bfloat16), C, split_k=split, accumulate=(split == 1))
+    assert_close(C, 2 * (dy.T @ x), f"TN accumulate {M}x{N}x{K} split{split}")
+
+
+def test_epilogue_bias_gelu_aux():
+    ops = _ops()
+    M, N, K = 513, 768, 192
+    a, w, b = rt(randn(M, K, seed=1)), rt(randn(N, K, seed=2, scale=K ** -0.5)), randn(N, seed=3, scale=0.1)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    Z = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(ops.NT, a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, bias=b.to(dev()), act=ops.ACT_GELU, aux=Z)
+    z = a @ w.T + b
+    assert_close(Z, z, "pre-activation")
+    assert_close(C, _gelu(z), "gelu")
+
+
+def test_epilogue_dgelu():
+    ops = _ops()
+    M, N, K = 260, 192, 768
+    dy, w, z = rt(randn(M, K, seed=1)), rt(randn(K, N, seed=2, scale=K ** -0.5)), rt(randn(M, N, seed=3))
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(ops.NN, dy.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, act=ops.ACT_DGELU, aux=z.to(dev(), torch.bfloat16))
+    assert_close(C, (dy @ w) * _dgelu(z), "dgelu")
+
+
+def test_epilogue_bias_residual_f32():
+    ops = _ops()
+    M, N, K = 1026, 768, 768
+    a, w, b, r = rt(randn(M, K, seed=1)), rt(randn(N, K, seed=2, scale=K ** -0.5)), randn(N, seed=3), randn(M, N, seed=4)
+    C = torch.empty(M, N, dtype=torch.float32, device=dev())
+    ops.gemm(ops.NT, a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, bias=b.to(dev()), residual=r.to(dev()))
+    assert_close(C, a @ w.T + b + r, "bias+residual")
+
+
+def test_epilogue_patch_embed_rows():
+    """pos broadcast by row modulo + the row remap that leaves the CLS row free (model_cross.py:194-197)."""
+    ops = _ops()
+    Bm, P, K, N = 3, 16, 128, 192
+    a, w, b = rt(randn(Bm * P, K, seed=1)), rt(randn(N, K, seed=2, scale=K ** -0.5)), randn(N, seed=3)
+    pos = randn(P + 1, N, seed=4)
+    X = torch.full((Bm * (P + 1), N), 7.0, dtype=torch.float32, device=dev())
+    ops.gemm(ops.NT, a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), X, bias=b.to(dev()), residual=pos.to(dev()),
+             res_row_mod=P, res_row_off=1, out_seg=(P, 1, 1), M=Bm * P)
+    ref = torch.full((Bm, P + 1, N), 7.0)
+    ref[:, 1:] = (a @ w.T + b).reshape(Bm, P, N) + pos[1:]
+    assert_close(X.reshape(Bm, P + 1, N), ref, "patch-embed epilogue")
+
+
+def test_batched_and_strided_views():
+    ops = _ops()
+    G, M, N, K = 2, 130, 192, 256
+    a, w = rt(randn(G, M, K, seed=1)), rt(randn(G, N, K, seed=2, scale=K ** -0.5))
+    bias = randn(G, N, seed=3)
+    C = torch.empty(G, M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(ops.NT, a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, bias=bias.to(dev()))
+    assert_close(C, torch.einsum("gmk,gnk->gmn", a, w) + bias[:, None], "batched NT")
+    # column-sliced operand (lda > K), e.g. rows of a [B*N, 3d] tensor
+    big = rt(randn(M, 3 * K, seed=5))
+    bd = big.to(dev(), torch.bfloat16)
+    C2 = torch.empty(M, N, dtype=torch.float32, device=dev())
+    ops.gemm(ops.NT, bd[:, K:2 * K], w[0].to(dev(), torch.bfloat16), C2)
+    assert_close(C2, big[:, K:2 * K] @ w[0].T, "strided A")
+
+
+def test_rejects_bad_arguments():
+    ops = _ops()
+    a = torch.zeros(64, 100, dtype=torch.bfloat16, device=dev())  # K=100 not a multiple of 64
+    w = torch.zeros(64, 100, dtype=torch.bfloat16, device=dev())
+    with pytest.raises((RuntimeError, AssertionError)):
+        ops.gemm(ops.NT, a[:, :96], w[:, :96], torch.empty(64, 64, dtype=torch.float32, device=dev()))
+    with pytest.raises(RuntimeError):
+        ops.gemm(ops.NT, torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 4))  # CPU tensors

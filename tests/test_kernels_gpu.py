@@ -1,0 +1,170 @@
+"""GPU parity for the non-GEMM kernels: LayerNorm, fused attention fwd/bwd, CLS cross-attention,
+patchify and the small helpers — each against the CPU oracle on the same bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+
+import ref_cpu as R
+from _util import assert_close, dev, randn, rel, rt
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from xvit import ops
+    return ops
+
+
+# ------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("rows,d", [(7, 192), (1026, 768), (130, 256), (65, 1024), (9, 2048)])
+def test_layernorm_fwd_bwd(rows, d):
+    ops = _ops()
+    x, g, b = randn(rows, d, seed=1) * 2 + 0.3, 1 + 0.1 * randn(d, seed=2), 0.1 * randn(d, seed=3)
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev()), g.to(dev()), b.to(dev()), 1e-5)
+    ref = R.layer_norm(x, g, b, 1e-5)
+    assert_close(y, ref, "ln fwd")
+    assert_close(mean, x.mean(-1), "mean")
+    # backward against autograd (dy is bf16 on the device: feed the oracle the same rounded values)
+    dy, dres = rt(randn(rows, d, seed=4)), randn(rows, d, seed=5)
+    xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    R.layer_norm(xr, gr, br, 1e-5).backward(dy)
+    dg = torch.zeros(d, device=dev()); db = torch.zeros(d, device=dev())
+    dx, dxb = ops.layernorm_bwd(dy.to(dev(), torch.bfloat16), x.to(dev()), mean, rstd, g.to(dev()), dg, db, dres=dres.to(dev()), want_bf16=True)
+    assert_close(dx, xr.grad + dres, "ln dx (+residual)")
+    assert_close(dxb, xr.grad + dres, "ln dx bf16 copy")
+    assert_close(dg, gr.grad, "dgamma")
+    assert_close(db, br.grad, "dbeta")
+
+
+def test_layernorm_row0_from_other_tensor():
+    """rows with n == 0 come from x_alt: the cat(cls_i, patches_j) of model_cross.py:140."""
+    ops = _ops()
+    B, N, d = 3, 17, 192
+    xi, xj = randn(B, N, d, seed=1), randn(B, N, d, seed=2)
+    g, b = 1 + 0.1 * randn(d, seed=3), 0.1 * randn(d, seed=4)
+    y, _, _ = ops.layernorm_fwd(xj.to(dev()).reshape(B * N, d), g.to(dev()), b.to(dev()), 1e-5, x_alt=xi.to(dev()).reshape(B * N, d), seq_len=N)
+    cat = torch.cat((xi[:, 0:1], xj[:, 1:]), dim=1)
+    assert_close(y.reshape(B, N, d), R.layer_norm(cat, g, b), "ln with x_alt")
+
+
+# ------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,H,N", [(2, 3, 17), (2, 2, 65), (1, 4, 130), (2, 12, 513), (1, 2, 64), (1, 1, 128), (1, 2, 1)])
+def test_attention_fwd_bwd(B, H, N):
+    ops = _ops()
+    d = H * 64
+    qkv = rt(randn(B, N, 3 * d, seed=N))
+    scale = 64 ** -0.5
+    o, lse = ops.attn_fwd(qkv.to(dev(), torch.bfloat16).reshape(B * N, 3 * d), B, N, H, scale)
+    q, k, v = (t.reshape(B, N, H, 64).permute(0, 2, 1, 3) for t in qkv.split(d, dim=-1))
+    qr, kr, vr = (t.clone().requires_grad_() for t in (q, k, v))
+    o_ref, lse_ref = R.softmax_attention(qr, kr, vr, scale)
+    assert_close(o.reshape(B, N, H, 64).permute(0, 2, 1, 3), o_ref, f"attn fwd N={N}")
+    assert_close(lse, lse_ref, "lse")
+    do = rt(randn(B, N, d, seed=N + 1))
+    o_ref.backward(do.reshape(B, N, H, 64).permute(0, 2, 1, 3))
+    # the kernel recomputes P from ITS bf16 O; use the device O for delta like the real pipeline does
+    dqkv = ops.attn_bwd(qkv.to(dev(), torch.bfloat16).reshape(B * N, 3 * d), o, do.to(dev(), torch.bfloat16).reshape(B * N, d), lse, B, N, H, scale)
+    dq, dk, dv = (t.reshape(B, N, H, 64).permute(0, 2, 1, 3) for t in dqkv.float().cpu().reshape(B, N, 3 * d).split(d, dim=-1))
+    assert rel(dv, vr.grad) < 4e-3, rel(dv, vr.grad)
+    if N == 1:  # a single key: softmax == 1, so dk = dq = 0 exactly; only round-off remains
+        assert float(dk.abs().max()) < 1e-5 and float(dq.abs().max()) < 1e-5
+    else:
+        assert rel(dk, kr.grad) < 6e-3, rel(dk, kr.grad)
+        assert rel(dq, qr.grad) < 6e-3, rel(dq, qr.grad)
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump at a late key tile (guide rule 26): one key aligned with one
+    query and scaled up, placed in the last tile."""
+    ops = _ops()
+    B, H, N = 1, 1, 200
+    qkv = rt(randn(B, N, 192, seed=5))
+    qkv[0, 190, 64:128] = rt(qkv[0, 3, 0:64] * 6.0)   # k[190] = 6 * q[3]
+    o, lse = ops.attn_fwd(qkv.to(dev(), torch.bfloat16).reshape(N, 192), B, N, H, 0.125)
+    q, k, v = (t.reshape(B, N, 1, 64).permute(0, 2, 1, 3) for t in qkv.split(64, dim=-1))
+    o_ref, lse_ref = R.softmax_attention(q, k, v, 0.125)
+    assert_close(o.reshape(B, N, 1, 64).permute(0, 2, 1, 3), o_ref, "rescale branch")
+    assert_close(lse, lse_ref, "rescale lse")
+
+
+# --------------------------------------------------------------------------- CLS cross-attention
+@pytest.mark.parametrize("B,H,N", [(2, 3, 17), (3, 4, 65), (2, 12, 513), (1, 2, 700)])
+def test_cls_xattn_fwd_bwd(B, H, N):
+    ops = _ops()
+    d = H * 64
+    scale = 0.125
+    qv, kv = rt(randn(B, d, seed=1)), rt(randn(B, N, 2 * d, seed=2))
+    o, p = ops.cls_xattn_fwd(qv.to(dev(), torch.bfloat16), kv.to(dev(), torch.bfloat16).reshape(B * N, 2 * d), B, N, H, scale)
+    q = qv.reshape(B, 1, H, 64).permute(0, 2, 1, 3).clone().requires_grad_()
+    k, v = (t.reshape(B, N, H, 64).permute(0, 2, 1, 3).clone().requires_grad_() for t in kv.split(d, dim=-1))
+    o_ref, _ = R.softmax_attention(q, k, v, scale)
+    assert_close(o, o_ref.permute(0, 2, 1, 3).reshape(B, d), "cls xattn fwd")
+    p_ref = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1).squeeze(2)
+    assert_close(p, p_ref, "cls xattn probs")
+    do = rt(randn(B, d, seed=3))
+    o_ref.backward(do.reshape(B, 1, H, 64).permute(0, 2, 1, 3))
+    dq, dkv = ops.cls_xattn_bwd(qv.to(dev(), torch.bfloat16), kv.to(dev(), torch.bfloat16).reshape(B * N, 2 * d), p, do.to(dev(), torch.bfloat16), B, N, H, scale)
+    assert_close(dq, q.grad.permute(0, 2, 1, 3).reshape(B, d), "dq")
+    dk, dv = (t.reshape(B, N, H, 64).permute(0, 2, 1, 3) for t in dkv.float().cpu().reshape(B, N, 2 * d).split(d, dim=-1))
+    assert rel(dk, k.grad) < 3e-3 and rel(dv, v.grad) < 3e-3
+
+
+# ------------------------------------------------------------------------------------ patchify
+@pytest.mark.parametrize("img_size,patch,dtype", [((32, 32, 2), (8, 8, 2), torch.float32), ((16, 24, 32), (8, 8, 16), torch.float32),
+                                                   ((32, 32, 16), (8, 8, 8), torch.bfloat16), ((32, 16, 32), (16, 16, 16), torch.float32)])
+def test_patchify_bit_exact(img_size, patch, dtype):
+    ops = _ops()
+    B, M = 2, 3
+    img = randn(B, M, 1, *img_size, seed=3).to(dtype)
+    out = ops.patchify(img.to(dev()), patch)
+    for m in range(M):
+        ref = R.patchify(img[:, m, 0].float(), patch).to(torch.bfloat16)  # pure permutation + one rounding
+        assert torch.equal(out[m].cpu().reshape(ref.shape), ref), f"patchify modality {m}"
+
+
+# ------------------------------------------------------------------------------------- helpers
+def test_colsum_cast_embed_small_linear_ce_dropout():
+    ops = _ops()
+    x = rt(randn(1026, 768, seed=1))
+    assert_close(ops.colsum(x.to(dev(), torch.bfloat16)), x.sum(0), "colsum bf16")
+    acc = torch.ones(768, device=dev())
+    ops.colsum(x.to(dev()), out=acc, accumulate=True)
+    assert_close(acc, x.sum(0) + 1, "colsum fp32 accumulate")
+    w = randn(1000, 37, seed=2)
+    assert torch.equal(ops.cast_bf16(w.to(dev())).cpu(), w.to(torch.bfloat16))
+    # embed: cls row + pos/cls grads
+    MB, N, d = 6, 17, 192
+    cls, pos = randn(d, seed=3), randn(N, d, seed=4)
+    xx = torch.zeros(MB, N, d, device=dev())
+    ops.cls_row_fwd(cls.to(dev()), pos.to(dev()), xx, MB, N, d)
+    assert_close(xx[:, 0].cpu(), (cls + pos[0]).expand(MB, d), "cls row")
+    assert float(xx[:, 1:].abs().max()) == 0.0
+    dx = randn(MB, N, d, seed=5)
+    dpos, dcls = torch.zeros(N, d, device=dev()), torch.zeros(d, device=dev())
+    ops.embed_bwd(dx.to(dev()), dpos, dcls, MB, N, d)
+    assert_close(dpos, dx.sum(0), "dpos"); assert_close(dcls, dx[:, 0].sum(0), "dcls")
+    # tiny head linear
+    xh, W, b = rt(randn(5, 768, seed=6)), randn(2, 768, seed=7), randn(2, seed=8)
+    y = ops.small_linear_fwd(xh.to(dev(), torch.bfloat16), W.to(dev()), b.to(dev()))
+    assert_close(y, xh @ W.T + b, "small linear fwd")
+    dy = randn(5, 2, seed=9)
+    dW, dbb = torch.zeros(2, 768, device=dev()), torch.zeros(2, device=dev())
+    dxh = ops.small_linear_bwd(dy.to(dev()), xh.to(dev(), torch.bfloat16), W.to(dev()), dW, dbb)
+    assert_close(dxh, dy @ W, "small linear dx"); assert_close(dW, dy.T @ xh, "small linear dW"); assert_close(dbb, dy.sum(0), "small linear db")
+    # mean + cross-entropy (label smoothing on and off)
+    for eps in (0.0, 0.1):
+        lm = randn(3, 7, 2, seed=10).requires_grad_()
+        labels = torch.tensor([0, 1, 1, 0, 1, 0, 0])
+        logits, loss, dl = ops.mean_ce(lm.detach().to(dev()), labels.to(dev()), eps)
+        ref_logits = lm.mean(0)
+        ref_loss = R.cross_entropy(ref_logits, labels, eps)
+        ref_loss.backward()
+        assert_close(logits, ref_logits, "mean logits"); assert abs(float(loss) - float(ref_loss)) < 1e-5
+        assert_close(dl, lm.grad, "dlogits")
+    # dropout: deterministic in (seed, index), right keep rate and scaling
+    xd = torch.ones(1 << 20, device=dev())
+    y1, y2, y3 = ops.dropout(xd, 0.25, 1234), ops.dropout(xd, 0.25, 1234), ops.dropout(xd, 0.25, 99)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    keep = float((y1 != 0).float().mean())
+    assert abs(keep - 0.75) < 5e-3 and abs(float(y1.max()) - 1 / 0.75) < 1e-6
