@@ -11,7 +11,7 @@ namespace xvit {
 // ------------------------------------------------------------------------------------------
 template <typename T, int VEC>
 __global__ void patchify_kernel(const T* __restrict__ img, bf16* __restrict__ out, int B, int M, int D, int H, int W, int dp, int hp, int wp,
-                                int64_t total_vec) {
+                                int pad, int64_t total_vec) {
   const int Wv = W / VEC;
   const int Dn = D / dp, Wn = W / wp;
   const int P = Dn * (H / hp) * Wn, pd = dp * hp * wp;
@@ -28,7 +28,7 @@ __global__ void patchify_kernel(const T* __restrict__ img, bf16* __restrict__ ou
     const int d = dd / dp, p1 = dd - d * dp;
     const int t = (h * Wn + w) * Dn + d;
     const int f = (p1 * hp + p2) * wp + p3;
-    bf16* dst = out + ((int64_t)(m * B + b) * P + t) * pd + f;
+    bf16* dst = out + ((int64_t)(m * B + b) * (P + pad) + t + pad) * pd + f;
     const T* src = img + idx * VEC;
     if constexpr (VEC == 8) {
       bf16x8 o;
@@ -42,6 +42,16 @@ __global__ void patchify_kernel(const T* __restrict__ img, bf16* __restrict__ ou
     } else {
       *dst = f2bf((float)*src);
     }
+  }
+}
+
+// zero row 0 of every [rows_per, pd] sample (the CLS slot of the padded patch matrix)
+__global__ void zero_rows_kernel(bf16* __restrict__ out, int samples, int64_t sample_stride, int pd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int pv = pd >> 3;
+  if (i < (int64_t)samples * pv) {
+    const int s = (int)(i / pv), c = (int)(i - (int64_t)s * pv);
+    ((bf16x8*)(out + s * sample_stride))[c] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
 }
 
@@ -123,12 +133,14 @@ __global__ void small_linear_fwd_kernel(const bf16* __restrict__ x, int64_t ldx,
 }
 
 __global__ void small_linear_bwd_kernel(const float* __restrict__ dy, const bf16* __restrict__ x, int64_t ldx, const float* __restrict__ W,
-                                        bf16* __restrict__ dx, int64_t lddx, float* __restrict__ dW, float* __restrict__ db, int M, int N, int K) {
+                                        const bf16* __restrict__ z, int64_t ldz, bf16* __restrict__ dx, int64_t lddx, float* __restrict__ dW,
+                                        float* __restrict__ db, int M, int N, int K) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < K) {
     for (int m = 0; m < M; ++m) {
       float acc = 0.f;
       for (int n = 0; n < N; ++n) acc = fmaf(dy[m * N + n], W[(int64_t)n * K + k], acc);
+      if (z) acc *= dgelu_f(bf2f(z[(int64_t)m * ldz + k]));
       dx[(int64_t)m * lddx + k] = f2bf(acc);
     }
     for (int n = 0; n < N; ++n) {
@@ -193,22 +205,29 @@ static int grid_for(int64_t work, int block) {
 }
 
 extern "C" int xvit_patchify(const void* img, int img_dtype, void* out, int B, int M, int D, int H, int W, int dp, int hp, int wp,
-                             xvit_stream_t stream) {
+                             int pad, xvit_stream_t stream) {
   XVIT_REQUIRE(img && out, "xvit_patchify: null pointer");
   XVIT_REQUIRE(B > 0 && M > 0 && D > 0 && H > 0 && W > 0 && dp > 0 && hp > 0 && wp > 0, "xvit_patchify: bad sizes");
   XVIT_REQUIRE(D % dp == 0 && H % hp == 0 && W % wp == 0, "xvit_patchify: image dimensions must be divisible by the patch size");
   XVIT_REQUIRE(img_dtype == XVIT_F32 || img_dtype == XVIT_BF16, "xvit_patchify: bad dtype");
+  XVIT_REQUIRE(pad == 0 || pad == 1, "xvit_patchify: pad_cls_row must be 0 or 1");
+  XVIT_REQUIRE(pad == 0 || (dp * hp * wp) % 8 == 0, "xvit_patchify: pad_cls_row needs patch_dim %% 8 == 0");
   const int64_t total = (int64_t)B * M * D * H * W;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (wp % 8 == 0) && ((reinterpret_cast<uintptr_t>(img) & 31) == 0);
   bf16* o = (bf16*)out;
   if (vec) {
     const int64_t tv = total / 8;
-    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, tv);
-    else hipLaunchKernelGGL((patchify_kernel<bf16, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, tv);
+    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, pad, tv);
+    else hipLaunchKernelGGL((patchify_kernel<bf16, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, pad, tv);
   } else {
-    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, total);
-    else hipLaunchKernelGGL((patchify_kernel<bf16, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, total);
+    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, pad, total);
+    else hipLaunchKernelGGL((patchify_kernel<bf16, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, pad, total);
+  }
+  if (pad) {
+    const int pd = dp * hp * wp, P = (D / dp) * (H / hp) * (W / wp);
+    const int64_t work = (int64_t)B * M * (pd / 8);
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, o, B * M, (int64_t)(P + 1) * pd, pd);
   }
   return check_launch("xvit_patchify");
 }
@@ -264,11 +283,11 @@ extern "C" int xvit_small_linear_fwd(const void* x, int64_t ldx, const float* W,
   return check_launch("xvit_small_linear_fwd");
 }
 
-extern "C" int xvit_small_linear_bwd(const float* dy, const void* x, int64_t ldx, const float* W, void* dx, int64_t lddx, float* dW, float* db, int M,
-                                     int N, int K, xvit_stream_t stream) {
+extern "C" int xvit_small_linear_bwd(const float* dy, const void* x, int64_t ldx, const float* W, const void* z, int64_t ldz, void* dx, int64_t lddx,
+                                     float* dW, float* db, int M, int N, int K, xvit_stream_t stream) {
   XVIT_REQUIRE(dy && x && W && dx && dW && db && M > 0 && N > 0 && K >= N, "xvit_small_linear_bwd: bad arguments");
-  hipLaunchKernelGGL(small_linear_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, (const bf16*)x, ldx, W, (bf16*)dx, lddx, dW, db, M,
-                     N, K);
+  hipLaunchKernelGGL(small_linear_bwd_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, dy, (const bf16*)x, ldx, W, (const bf16*)z, ldz, (bf16*)dx,
+                     lddx, dW, db, M, N, K);
   return check_launch("xvit_small_linear_bwd");
 }
 

@@ -1,5 +1,11 @@
 """xvit — MI355X-native hot path of the cross-attention 3-D ViT, behind the reference's
-own nn.Module signatures (vsahni3/cross-attention-ViT: model_cross.py, model.py)."""
-from . import _lib  # noqa: F401
+own nn.Module signatures (vsahni3/cross-attention-ViT: model_cross.py, model.py).
 
-__all__ = ["_lib"]
+    from xvit.model_cross import ModelCross          # drop-in for reference model_cross.ModelCross
+    from xvit.model import Encoder                   # drop-in for reference model.Encoder
+"""
+from . import _lib  # noqa: F401
+from .functional import invalidate_shadows  # noqa: F401
+from .model import Block, Encoder, Mlp, MultiHeadAttention  # noqa: F401
+from .model_cross import (Attention, CrossAttention, CrossAttentionBlock, FeedForward, ModelCross,  # noqa: F401
+                          MultiScaleBlock, PreNorm, SelfAttentionBlock)

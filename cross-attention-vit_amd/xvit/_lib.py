@@ -26,14 +26,14 @@ class GemmArgs(C.Structure):
 SIGNATURES = {
     "xvit_gemm": [C.POINTER(GemmArgs), vp],
     "xvit_small_linear_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
-    "xvit_small_linear_bwd": [vp, vp, i64, vp, vp, i64, vp, vp, i32, i32, i32, vp],
+    "xvit_small_linear_bwd": [vp, vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp],
     "xvit_layernorm_fwd": [vp, vp, i64, i32, vp, vp, f32, vp, i64, vp, vp, i32, i32, vp],
     "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, vp],
     "xvit_attn_fwd": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, vp],
     "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "xvit_cls_xattn_fwd": [vp, i64, vp, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp],
     "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, f32, vp],
-    "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "xvit_cls_row_fwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_embed_bwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_cast_f32_bf16": [vp, vp, i64, vp],

@@ -1,0 +1,252 @@
+"""Drop-in replacements for the reference's model_cross.py modules (re-exported by
+xvit/model_cross.py under the reference's module name).
+
+Same class names, constructor arguments, forward signatures and state_dict keys as
+/root/reference/model_cross.py; the arithmetic runs on the HIP kernels of
+libxvit_hip.so.  Parameters are ordinary fp32 nn.Parameters (so torch.optim.Adam, DDP and
+Lightning checkpoints work unchanged); nn.Linear / nn.LayerNorm objects are used ONLY as
+parameter containers with the reference's names — their torch forward is never called.
+
+`config` is duck-typed: any object with the attributes config2.py / main_mist.py set.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as XF
+
+try:  # the reference derives ModelCross from lightning.LightningModule (model_cross.py:152)
+    import lightning as _L  # type: ignore
+
+    _Base = _L.LightningModule
+except Exception:  # lightning is not installed on this image: plain nn.Module, same methods
+    _Base = nn.Module
+
+
+def _lin(i, o, bias=True):
+    return nn.Linear(i, o, bias=bias)
+
+
+def _mlp_container(config, out_dim):
+    """Parameter container with the reference's child indices: 0 = Linear(d, f), 3 = Linear(f, out)."""
+    return nn.Sequential(_lin(config.hidden_dim, config.mlp_dim), nn.GELU(), nn.Dropout(config.dropout),
+                         _lin(config.mlp_dim, out_dim), nn.Dropout(config.dropout))
+
+
+def _check_dropout(module, p):
+    if module.training and p > 0.0:
+        raise NotImplementedError(
+            "xvit: dropout > 0 in training mode is not wired into the fused HIP blocks yet "
+            "(parity is defined at dropout = 0 / eval); set config.dropout = 0 or call .eval()")
+
+
+class PreNorm(nn.Module):
+    """model_cross.py:11-17."""
+
+    def __init__(self, config, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(config.hidden_dim)
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        return self.fn(XF.LayerNormFn.apply(x, self.norm.weight, self.norm.bias, self.norm.eps), **kwargs)
+
+
+class FeedForward(nn.Module):
+    """model_cross.py:19-31."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.net = _mlp_container(config, config.hidden_dim)
+
+    def forward(self, x):
+        _check_dropout(self, self.net[2].p)
+        return XF.FeedForwardFn.apply(x, self.net[0].weight, self.net[0].bias, self.net[3].weight, self.net[3].bias)
+
+
+class Attention(nn.Module):
+    """model_cross.py:33-61."""
+
+    def __init__(self, config, dim_head):
+        super().__init__()
+        d, H = config.hidden_dim, config.num_heads
+        if dim_head * H != d:
+            raise AssertionError(f"dim_head * num_heads ({dim_head}*{H}) must equal hidden_dim ({d})")
+        self.heads, self.scale = H, dim_head ** -0.5
+        self.to_qkv = _lin(d, 3 * d, bias=False)                       # fused q|k|v, no bias
+        single = H == 1 and dim_head == d
+        self.to_out = nn.Identity() if single else nn.Sequential(_lin(d, d), nn.Dropout(config.dropout))
+
+    def forward(self, x):
+        qkv = XF.LinearFn.apply(x, self.to_qkv.weight, None, False)
+        out = XF.AttentionCoreFn.apply(qkv, self.heads, self.scale)
+        if isinstance(self.to_out, nn.Identity):
+            return out
+        _check_dropout(self, self.to_out[1].p)
+        return XF.LinearFn.apply(out, self.to_out[0].weight, self.to_out[0].bias, True)
+
+
+class SelfAttentionBlock(nn.Module):
+    """model_cross.py:64-72 — one fused autograd node (XF.SelfAttentionBlockFn)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.attn = PreNorm(config, Attention(config, dim_head=(config.hidden_dim // config.num_heads)))
+        self.ffn = PreNorm(config, FeedForward(config))
+
+    def forward(self, x):
+        a, f = self.attn, self.ffn
+        if isinstance(a.fn.to_out, nn.Identity):  # single-head degenerate case: unfused composition
+            x = a(x) + x
+            return f(x) + x
+        _check_dropout(self, f.fn.net[2].p)
+        return XF.SelfAttentionBlockFn.apply(
+            x, a.norm.weight, a.norm.bias, a.fn.to_qkv.weight, a.fn.to_out[0].weight, a.fn.to_out[0].bias,
+            f.norm.weight, f.norm.bias, f.fn.net[0].weight, f.fn.net[0].bias, f.fn.net[3].weight, f.fn.net[3].bias,
+            a.fn.heads, a.norm.eps)
+
+
+class CrossAttention(nn.Module):
+    """model_cross.py:74-102: the query is the CLS row only."""
+
+    def __init__(self, config):
+        super().__init__()
+        d = config.hidden_dim
+        self.num_heads = config.num_heads
+        self.scale = (d // self.num_heads) ** -0.5
+        for name in ("wq", "wk", "wv", "proj"):
+            setattr(self, name, _lin(d, d))
+        self.attn_drop, self.proj_drop = nn.Dropout(config.dropout), nn.Dropout(config.dropout)
+
+    def forward(self, x):
+        _check_dropout(self, self.attn_drop.p)
+        B, N, C = x.shape
+        q = XF.LinearFn.apply(x[:, 0], self.wq.weight, self.wq.bias, False)
+        k = XF.LinearFn.apply(x, self.wk.weight, self.wk.bias, False)
+        v = XF.LinearFn.apply(x, self.wv.weight, self.wv.bias, False)
+        o = XF.ClsAttentionCoreFn.apply(q, torch.cat((k, v), dim=-1), self.num_heads, self.scale)
+        return XF.LinearFn.apply(o, self.proj.weight, self.proj.bias, True).reshape(B, 1, C)
+
+
+def _fusion_args(blk):
+    a, f = blk.attn, blk.ffn
+    c = a.fn
+    return (a.norm.weight, a.norm.bias, c.wq.weight, c.wq.bias, c.wk.weight, c.wk.bias, c.wv.weight, c.wv.bias,
+            c.proj.weight, c.proj.bias, f.norm.weight, f.norm.bias, f.fn.net[0].weight, f.fn.net[0].bias,
+            f.fn.net[3].weight, f.fn.net[3].bias, c.num_heads, a.norm.eps)
+
+
+class CrossAttentionBlock(nn.Module):
+    """model_cross.py:104-114: [B, N, d] -> [B, 1, d]."""
+
+    def __init__(self, config, act_layer=nn.GELU):
+        super().__init__()
+        self.attn = PreNorm(config, CrossAttention(config))
+        self.ffn = PreNorm(config, FeedForward(config))
+
+    def forward(self, x):
+        _check_dropout(self, self.attn.fn.attn_drop.p)
+        return XF.CrossFusionFn.apply(x, x, *_fusion_args(self), False)
+
+
+class MultiScaleBlock(nn.Module):
+    """model_cross.py:116-148: list of M token tensors in, list out."""
+
+    def __init__(self, config, act_layer=nn.GELU):
+        super().__init__()
+        self.attn_order = config.attn_order        # {str(cls modality): str(token modality)}
+        branch = lambda: nn.Sequential(*(SelfAttentionBlock(config) for _ in range(config.num_self_blocks)))  # noqa: E731
+        self.blocks = nn.ModuleList(branch() for _ in range(config.num_modalities))   # separate weights per modality
+        self.fusion = nn.ModuleList(CrossAttentionBlock(config) for _ in self.attn_order)
+
+    def forward(self, x):
+        attn = [block(x_) for x_, block in zip(x, self.blocks)]
+        outs = []
+        cross_count = 0
+        for i in range(len(self.blocks)):
+            if str(i) in self.attn_order:
+                j = int(self.attn_order[str(i)])
+                blk = self.fusion[cross_count]
+                _check_dropout(blk, blk.attn.fn.attn_drop.p)
+                # cls of i + patch tokens of j -> new cls, re-attached to i's own patch tokens (:140-142)
+                outs.append(XF.CrossFusionFn.apply(attn[i], attn[j], *_fusion_args(blk), True))
+                cross_count += 1
+            else:
+                outs.append(attn[i])
+        return outs
+
+
+class ModelCross(_Base):
+    """model_cross.py:152-308.  forward(img [B, M, 1, D, H, W], labels [B]) -> (logits, loss)."""
+
+    def __init__(self, config):
+        super().__init__()
+        grid = [s // p for s, p in zip(config.img_size, config.patch_size)]
+        if any(s % p for s, p in zip(config.img_size, config.patch_size)):
+            raise AssertionError('image dimensions must be divisible by the patch size')
+        P, pd, d, M = grid[0] * grid[1] * grid[2], config.patch_size[0] * config.patch_size[1] * config.patch_size[2], config.hidden_dim, config.num_modalities
+        self.patch_size = tuple(config.patch_size)
+        self.num_modalities = M
+        for k in ("lr", "weight_decay", "optim_params", "label_smoothing"):
+            setattr(self, k, getattr(config, k))
+        # shared by every modality (model_cross.py:167-169)
+        self.pos_embedding = nn.Parameter(torch.empty(1, P + 1, d))
+        self.patch_to_embedding = _lin(pd, d)
+        self.cls_token = nn.Parameter(torch.empty(1, 1, d))
+        self.dropout = nn.Dropout(config.dropout)
+        self.transformer = nn.Sequential(*(MultiScaleBlock(config) for _ in range(config.num_multi_blocks)))
+        self.norm = nn.ModuleList(nn.LayerNorm(d) for _ in range(M))
+        self.mlp_head = nn.ModuleList(_mlp_container(config, config.num_classes) for _ in range(M))
+        self.initialize_model()
+
+    def forward(self, img, labels):
+        _check_dropout(self, self.dropout.p)
+        if img.shape[1] != self.num_modalities:
+            raise ValueError(f"expected {self.num_modalities} modalities, got {img.shape[1]}")
+        tokens = XF.PatchEmbedFn.apply(img, self.patch_to_embedding.weight, self.patch_to_embedding.bias,
+                                       self.cls_token, self.pos_embedding, self.patch_size)
+        x = self.transformer([tokens[m] for m in range(self.num_modalities)])
+        per_mod = [XF.HeadFn.apply(x[m], self.norm[m].weight, self.norm[m].bias, self.mlp_head[m][0].weight, self.mlp_head[m][0].bias,
+                                   self.mlp_head[m][3].weight, self.mlp_head[m][3].bias, self.norm[m].eps)
+                   for m in range(self.num_modalities)]
+        logits, loss = XF.MeanCrossEntropyFn.apply(torch.stack(per_mod), labels, self.label_smoothing)
+        return logits, loss
+
+    # ---- initialisation (model_cross.py:214-241) -------------------------------------------
+    @staticmethod
+    def init_weights(module):
+        if isinstance(module, nn.Linear):
+            nn.init.xavier_uniform_(module.weight)
+            if module.bias is not None:
+                nn.init.zeros_(module.bias)
+        elif isinstance(module, nn.LayerNorm):
+            nn.init.ones_(module.weight)
+            nn.init.zeros_(module.bias)
+
+    def initialize_model(self):
+        self.apply(ModelCross.init_weights)
+        nn.init.normal_(self.pos_embedding, mean=0.0, std=0.02)
+        nn.init.normal_(self.cls_token, mean=0.0, std=0.02)
+
+    # ---- training-loop surface used by main_mist.py / Lightning (model_cross.py:243-308) -----
+    def log(self, *args, **kwargs):  # no-op unless the Lightning base provides it
+        sup = getattr(super(), "log", None)
+        if sup is not None:
+            return sup(*args, **kwargs)
+
+    def training_step(self, batch, batch_idx):
+        x, labels = batch
+        logits, loss = self(x, labels)
+        self.log('train_loss', loss, on_epoch=True, on_step=False, sync_dist=True)
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        x, labels = batch
+        logits, loss = self(x, labels)
+        self.log('val_loss', loss, on_epoch=True, on_step=False, sync_dist=True)
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=self.optim_params["T_max"], eta_min=self.optim_params["eta_min"])
+        return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "interval": "epoch"}}

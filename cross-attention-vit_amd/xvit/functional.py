@@ -1,0 +1,518 @@
+"""Autograd layer: one torch.autograd.Function per reference block, each with a hand-written
+backward chain over the HIP kernels (fused residual + LayerNorm gradients, GELU' in the dgrad
+epilogue, wgrad by k-strided MFMA tiles, flash-attention recompute).  torch provides the
+tensors, the stream and the autograd graph edges between blocks — nothing else.
+
+Numerics: operands bf16, accumulation fp32, residual stream / LN statistics / parameter
+gradients fp32.  Weights are fp32 master parameters; their bf16 operand copies ("shadows")
+are re-cast whenever a parameter's version changes (i.e. after every optimizer step).
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+# ------------------------------------------------------------------------------------------
+# bf16 shadows of fp32 master weights
+# ------------------------------------------------------------------------------------------
+
+
+class _ShadowCache:
+    """bf16 operand copies of fp32 master weights, keyed by the Parameter OBJECT (weakly held, so
+    a recycled id() or device address can never return another tensor's copy) and refreshed when
+    its version counter or storage changes.  Non-Parameter tensors are cast fresh every time."""
+
+    def __init__(self):
+        self._map = {}
+        self.casts = 0
+
+    @staticmethod
+    def _cast(params):
+        with torch.no_grad():
+            if len(params) == 1:
+                return ops.cast_bf16(params[0].detach().contiguous())
+            rows = sum(p.shape[0] for p in params)
+            out = torch.empty(rows, *params[0].shape[1:], dtype=torch.bfloat16, device=params[0].device)
+            r = 0
+            for p in params:
+                ops.cast_bf16(p.detach().contiguous(), out[r:r + p.shape[0]])
+                r += p.shape[0]
+            return out
+
+    def get(self, *params):
+        """bf16 copy of one parameter, or of several concatenated along dim 0."""
+        self.casts += len(params)
+        if not all(isinstance(p, torch.nn.Parameter) for p in params):
+            self.casts += 0
+            return self._cast(params)
+        key = tuple(id(p) for p in params)
+        tag = tuple((p._version, p.data_ptr()) for p in params)
+        ent = self._map.get(key)
+        if ent is not None and ent[1] == tag and all(r() is p for r, p in zip(ent[0], params)):
+            self.casts -= len(params)
+            return ent[2]
+        out = self._cast(params)
+        if len(self._map) > 4096:  # dead models: drop entries whose parameters are gone
+            self._map = {k: v for k, v in self._map.items() if all(r() is not None for r in v[0])}
+        self._map[key] = (tuple(weakref.ref(p) for p in params), tag, out)
+        return out
+
+    def invalidate(self):
+        self._map.clear()
+
+
+SHADOWS = _ShadowCache()
+
+
+def invalidate_shadows():
+    """Drop every cached bf16 weight copy (they are re-cast on next use).  A training loop
+    does not need this: optimizer steps bump the parameter version.  bench.py calls it every
+    step because it skips the optimizer but must still pay for the per-step cast."""
+    SHADOWS.invalidate()
+
+
+# ------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------
+
+
+def _wgrad_split(m, n, k):
+    """Split-K factor for a TN wgrad: enough workgroups to fill 256 CUs, >= 8 K-steps each."""
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    ksteps = (k + 63) // 64
+    s = max(1, min(512 // max(tiles, 1), ksteps // 8, 32))
+    return s
+
+
+def _wgrad(dy_b, x_b):
+    """dW[out, in] = dy^T x over all rows (tokens); fp32."""
+    out_f, in_f, k = dy_b.shape[1], x_b.shape[1], dy_b.shape[0]
+    s = _wgrad_split(out_f, in_f, k)
+    dW = (torch.zeros if s > 1 else torch.empty)(out_f, in_f, dtype=torch.float32, device=dy_b.device)
+    ops.gemm(ops.TN, dy_b, x_b, dW, split_k=s)
+    return dW
+
+
+def _linear(x_b, w_s, *, bias=None, residual=None, act=ops.ACT_NONE, aux=None, out_dtype=torch.bfloat16, **kw):
+    y = torch.empty(x_b.shape[0], w_s.shape[0], dtype=out_dtype, device=x_b.device)
+    return ops.gemm(ops.NT, x_b, w_s, y, bias=bias, residual=residual, act=act, aux=aux, **kw)
+
+
+def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None):
+    dx = torch.empty(dy_b.shape[0], w_s.shape[1], dtype=torch.bfloat16, device=dy_b.device)
+    return ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux)
+
+
+def _zeros(n, ref):
+    return torch.zeros(n, dtype=torch.float32, device=ref.device)
+
+
+def _f32c(t):
+    t = t if t.dtype == torch.float32 else t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------
+# pre-norm transformer block:  x + attn(LN(x)) ;  x + ffn(LN(x))
+#   reference model_cross.py:64-72 (SelfAttentionBlock) and model.py:181-201 (Block)
+# ------------------------------------------------------------------------------------------
+
+
+def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln2w, ln2b, w1_s, b1, w2_s, b2):
+    """x fp32 [B*N, d] -> (x2 fp32 [B*N, d], saved activations)."""
+    h1, mu1, rs1 = ops.layernorm_fwd(x, ln1w, ln1b, eps)
+    qkv = _linear(h1, wqkv_s, bias=bqkv)
+    o, lse = ops.attn_fwd(qkv, B, N, H, scale)
+    x1 = _linear(o, wo_s, bias=bo, residual=x, out_dtype=torch.float32)
+    h2, mu2, rs2 = ops.layernorm_fwd(x1, ln2w, ln2b, eps)
+    z = torch.empty(x.shape[0], w1_s.shape[0], dtype=torch.bfloat16, device=x.device)
+    a = _linear(h2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z)
+    x2 = _linear(a, w2_s, bias=b2, residual=x1, out_dtype=torch.float32)
+    return x2, (x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a)
+
+
+def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w, w1_s, w2_s, need_dx=True):
+    """dy fp32 [B*N, d] -> (dx, grads dict)."""
+    x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a = saved
+    d = x.shape[1]
+    g = {}
+    dyb = ops.cast_bf16(dy)
+    # FFN
+    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z)
+    g["w2"] = _wgrad(dyb, a)
+    g["b2"] = ops.colsum(dy)
+    dh2 = _dgrad(dz, w1_s)
+    g["w1"] = _wgrad(dz, h2)
+    g["b1"] = ops.colsum(dz)
+    g["ln2w"], g["ln2b"] = _zeros(d, x), _zeros(d, x)
+    dx1, dx1b = ops.layernorm_bwd(dh2, x1, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy, want_bf16=True)
+    # attention
+    do = _dgrad(dx1b, wo_s)
+    g["wo"] = _wgrad(dx1b, o)
+    g["bo"] = ops.colsum(dx1)
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale)
+    dh1 = _dgrad(dqkv, wqkv_s)
+    g["wqkv"] = _wgrad(dqkv, h1)
+    if has_bqkv:
+        g["bqkv"] = ops.colsum(dqkv)
+    g["ln1w"], g["ln1b"] = _zeros(d, x), _zeros(d, x)
+    dx, _ = ops.layernorm_bwd(dh1, x, mu1, rs1, ln1w, g["ln1w"], g["ln1b"], dres=dx1)
+    return dx, g
+
+
+class SelfAttentionBlockFn(Function):
+    """model_cross.SelfAttentionBlock: fused-qkv (no bias), eps 1e-5, scale dh**-0.5."""
+
+    @staticmethod
+    def forward(ctx, x, ln1w, ln1b, wqkv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps):
+        B, N, d = x.shape
+        scale = (d // H) ** -0.5
+        sh = (SHADOWS.get(wqkv), SHADOWS.get(wo), SHADOWS.get(w1), SHADOWS.get(w2))
+        x2, saved = block_forward(_f32c(x).reshape(B * N, d), B, N, H, eps, scale, ln1w, ln1b, sh[0], None, sh[1], bo, ln2w, ln2b, sh[2], b1, sh[3], b2)
+        ctx.meta = (B, N, H, scale, x.dtype)
+        ctx.save_for_backward(ln1w, ln2w, *sh, *saved)
+        return x2.reshape(B, N, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, H, scale, xdt = ctx.meta
+        ln1w, ln2w, wqkv_s, wo_s, w1_s, w2_s, *saved = ctx.saved_tensors
+        dx, g = block_backward(_f32c(dy).reshape(B * N, -1), saved, B, N, H, scale, ln1w, wqkv_s, False, wo_s, ln2w, w1_s, w2_s)
+        return (dx.reshape(B, N, -1).to(xdt), g["ln1w"], g["ln1b"], g["wqkv"], g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None)
+
+
+class EncoderBlockFn(Function):
+    """model.Block: separate biased query/key/value, eps 1e-6, scores / sqrt(dh)."""
+
+    @staticmethod
+    def forward(ctx, x, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps):
+        B, N, d = x.shape
+        scale = 1.0 / float(d // H) ** 0.5
+        sh = (SHADOWS.get(wq, wk, wv), SHADOWS.get(wo), SHADOWS.get(w1), SHADOWS.get(w2))
+        bqkv = torch.cat((bq, bk, bv)).detach()
+        x2, saved = block_forward(_f32c(x).reshape(B * N, d), B, N, H, eps, scale, ln1w, ln1b, sh[0], bqkv, sh[1], bo, ln2w, ln2b, sh[2], b1, sh[3], b2)
+        ctx.meta = (B, N, H, scale, d, x.dtype)
+        ctx.save_for_backward(ln1w, ln2w, *sh, *saved)
+        return x2.reshape(B, N, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, H, scale, d, xdt = ctx.meta
+        ln1w, ln2w, wqkv_s, wo_s, w1_s, w2_s, *saved = ctx.saved_tensors
+        dx, g = block_backward(_f32c(dy).reshape(B * N, -1), saved, B, N, H, scale, ln1w, wqkv_s, True, wo_s, ln2w, w1_s, w2_s)
+        wq, wk, wv = g["wqkv"].split(d, dim=0)
+        bq, bk, bv = g["bqkv"].split(d)
+        return (dx.reshape(B, N, -1).to(xdt), g["ln1w"], g["ln1b"], wq, bq, wk, bk, wv, bv, g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None)
+
+
+# ------------------------------------------------------------------------------------------
+# cross-attention fusion (model_cross.py:104-114 CrossAttentionBlock, :135-142 routing)
+# ------------------------------------------------------------------------------------------
+
+
+def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq_s, bq, wkv_s, bkv, wp_s, bp, ln2w, ln2b, w1_s, b1, w2_s, b2):
+    """xi, xj fp32 [B*N, d] (cls taken from xi, patch tokens from xj) -> (y2 fp32 [B, d], saved)."""
+    d = xi.shape[1]
+    scale = (d // H) ** -0.5
+    hn, mu, rs = ops.layernorm_fwd(xj, ln1w, ln1b, eps, x_alt=xi, seq_len=N)
+    kv = _linear(hn, wkv_s, bias=bkv)
+    hn0 = hn.reshape(B, N * d)[:, :d]                      # the B normed CLS rows, ld = N*d
+    q = _linear(hn0, wq_s, bias=bq)
+    oc, p = ops.cls_xattn_fwd(q, kv, B, N, H, scale)
+    cls_in = xi.reshape(B, N * d)[:, :d]                   # un-normed CLS rows (the residual, :112)
+    y = _linear(oc, wp_s, bias=bp, residual=cls_in, out_dtype=torch.float32)
+    h2, mu2, rs2 = ops.layernorm_fwd(y, ln2w, ln2b, eps)
+    z = torch.empty(B, w1_s.shape[0], dtype=torch.bfloat16, device=xi.device)
+    a = _linear(h2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z)
+    y2 = _linear(a, w2_s, bias=b2, residual=y, out_dtype=torch.float32)
+    return y2, (xi, xj, mu, rs, hn, kv, q, oc, p, y, mu2, rs2, h2, z, a)
+
+
+def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s):
+    """dy2 fp32 [B, d] -> (dcat fp32 [B*N, d] = grad of the normed concat input, dcls_res fp32 [B, d], grads)."""
+    xi, xj, mu, rs, hn, kv, q, oc, p, y, mu2, rs2, h2, z, a = saved
+    d = xi.shape[1]
+    scale = (d // H) ** -0.5
+    g = {}
+    dyb = ops.cast_bf16(dy2)
+    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z)
+    g["w2"] = _wgrad(dyb, a)
+    g["b2"] = ops.colsum(dy2)
+    dh2 = _dgrad(dz, w1_s)
+    g["w1"] = _wgrad(dz, h2)
+    g["b1"] = ops.colsum(dz)
+    g["ln2w"], g["ln2b"] = _zeros(d, xi), _zeros(d, xi)
+    dy, dyb1 = ops.layernorm_bwd(dh2, y, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy2, want_bf16=True)
+    doc = _dgrad(dyb1, wp_s)
+    g["wp"] = _wgrad(dyb1, oc)
+    g["bp"] = ops.colsum(dy)
+    dq, dkv = ops.cls_xattn_bwd(q, kv, p, doc, B, N, H, scale)
+    dqb = ops.cast_bf16(dq)
+    dhn = _dgrad(dkv, wkv_s)                                # [B*N, d] bf16
+    dhq = _dgrad(dqb, wq_s)                                 # [B, d] bf16: the query path reaches row 0 only
+    dhn0 = dhn.reshape(B, N * d)[:, :d]
+    dhn0.copy_(dhn0.float() + dhq.float())                  # B rows: merge the two paths into the CLS rows
+    hn0 = hn.reshape(B, N * d)[:, :d]
+    g["wkv"] = _wgrad(dkv, hn)
+    g["bkv"] = ops.colsum(dkv)
+    g["wq"] = _wgrad(dqb, hn0)
+    g["bq"] = ops.colsum(dq)
+    g["ln1w"], g["ln1b"] = _zeros(d, xi), _zeros(d, xi)
+    dcat, _ = ops.layernorm_bwd(dhn, xj, mu, rs, ln1w, g["ln1w"], g["ln1b"], x_alt=xi, seq_len=N)
+    return dcat, dy, g
+
+
+class CrossFusionFn(Function):
+    """out_i = cat(CrossAttentionBlock(cat(cls_i, patches_j)), patches_i)  (model_cross.py:140-142)."""
+
+    @staticmethod
+    def forward(ctx, xi, xj, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wp, bp, ln2w, ln2b, w1, b1, w2, b2, H, eps, concat):
+        B, N, d = xi.shape
+        sh = (SHADOWS.get(wq), SHADOWS.get(wk, wv), SHADOWS.get(wp), SHADOWS.get(w1), SHADOWS.get(w2))
+        bkv = torch.cat((bk, bv)).detach()
+        xi2, xj2 = _f32c(xi).reshape(B * N, d), _f32c(xj).reshape(B * N, d)
+        y2, saved = cross_forward(xi2, xj2, B, N, H, eps, ln1w, ln1b, sh[0], bq, sh[1], bkv, sh[2], bp, ln2w, ln2b, sh[3], b1, sh[4], b2)
+        ctx.meta = (B, N, H, d, concat)
+        ctx.save_for_backward(ln1w, ln2w, *sh, *saved)
+        if not concat:
+            return y2.reshape(B, 1, d)
+        out = xi2.clone().reshape(B, N, d)
+        out[:, 0] = y2
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, N, H, d, concat = ctx.meta
+        ln1w, ln2w, wq_s, wkv_s, wp_s, w1_s, w2_s, *saved = ctx.saved_tensors
+        dout = _f32c(dout)
+        dy2 = dout[:, 0].contiguous()
+        dcat, dcls_res, g = cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s)
+        dcat = dcat.reshape(B, N, d)
+        # cls row -> x_i (normed-concat path + the un-normed residual path); patch rows -> x_j
+        if concat:
+            dxi = dout.clone()
+        else:
+            dxi = torch.zeros(B, N, d, dtype=torch.float32, device=dout.device)
+        dxi[:, 0] = dcat[:, 0] + dcls_res
+        dxj = dcat
+        dxj[:, 0] = 0
+        wk, wv = g["wkv"].split(d, dim=0)
+        bk, bv = g["bkv"].split(d)
+        return (dxi, dxj, g["ln1w"], g["ln1b"], g["wq"], g["bq"], wk, bk, wv, bv, g["wp"], g["bp"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None)
+
+
+# ------------------------------------------------------------------------------------------
+# patch embedding of all modalities at once (model_cross.py:191-199)
+# ------------------------------------------------------------------------------------------
+
+
+class PatchEmbedFn(Function):
+    """img [B, M, 1, D, H, W] -> tokens fp32 [M, B, N, d] = cat(cls, patches W^T + b) + pos."""
+
+    @staticmethod
+    def forward(ctx, img, w, b, cls, pos, patch):
+        Bn, M = img.shape[0], img.shape[1]
+        d, pd = w.shape
+        patches = ops.patchify(img.contiguous(), patch, pad_cls_row=True).reshape(-1, pd)   # [M*B*N, pd], row 0 of each sample = 0
+        N = patches.shape[0] // (M * Bn)
+        w_s = SHADOWS.get(w)
+        pos2 = pos.detach().reshape(N, d)
+        x = torch.empty(M * Bn * N, d, dtype=torch.float32, device=img.device)
+        ops.gemm(ops.NT, patches, w_s, x, bias=b, residual=pos2, res_row_mod=N, res_row_off=0)
+        ops.cls_row_fwd(cls.detach().reshape(d), pos2, x, M * Bn, N, d)
+        ctx.meta = (M, Bn, N, d)
+        ctx.save_for_backward(patches)
+        return x.reshape(M, Bn, N, d)
+
+    @staticmethod
+    def backward(ctx, dx):
+        M, Bn, N, d = ctx.meta
+        (patches,) = ctx.saved_tensors
+        dx2 = _f32c(dx).reshape(M * Bn * N, d)
+        dxb = ops.cast_bf16(dx2)
+        dW = _wgrad(dxb, patches)            # the zero CLS rows of `patches` drop the CLS-row gradients
+        dpos = torch.zeros(N, d, dtype=torch.float32, device=dx.device)
+        dcls = torch.zeros(d, dtype=torch.float32, device=dx.device)
+        ops.embed_bwd(dx2, dpos, dcls, M * Bn, N, d)
+        db = ops.colsum(dpos[1:])            # bias reaches the P patch rows of every sample
+        return None, dW, db, dcls.reshape(1, 1, d), dpos.reshape(1, N, d), None
+
+
+# ------------------------------------------------------------------------------------------
+# heads + loss (model_cross.py:203-211)
+# ------------------------------------------------------------------------------------------
+
+
+class HeadFn(Function):
+    """logits_m = Linear(GELU(Linear(LN(x)[:, 0]))): only the CLS row of the final norm is used."""
+
+    @staticmethod
+    def forward(ctx, x, lnw, lnb, w0, b0, w3, b3, eps):
+        B, N, d = x.shape
+        x2 = _f32c(x).reshape(B, N * d)[:, :d]              # CLS rows, ld = N*d
+        h, mu, rs = ops.layernorm_fwd(x2, lnw, lnb, eps)
+        w0_s = SHADOWS.get(w0)
+        z = torch.empty(B, w0.shape[0], dtype=torch.bfloat16, device=x.device)
+        a = _linear(h, w0_s, bias=b0, act=ops.ACT_GELU, aux=z)
+        logits = ops.small_linear_fwd(a, w3.detach(), b3.detach())
+        ctx.meta = (B, N, d)
+        ctx.save_for_backward(x2, mu, rs, h, z, a, lnw, w0_s, w3)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dl):
+        B, N, d = ctx.meta
+        x2, mu, rs, h, z, a, lnw, w0_s, w3 = ctx.saved_tensors
+        dl = _f32c(dl)
+        dW3, db3 = torch.zeros_like(w3), _zeros(w3.shape[0], dl)
+        dz = ops.small_linear_bwd(dl, a, w3.detach(), dW3, db3, z=z)
+        dh = _dgrad(dz, w0_s)
+        dW0 = _wgrad(dz, h)
+        db0 = ops.colsum(dz)
+        dg, dbeta = _zeros(d, dl), _zeros(d, dl)
+        dxc, _ = ops.layernorm_bwd(dh, x2, mu, rs, lnw, dg, dbeta)
+        dx = torch.zeros(B, N, d, dtype=torch.float32, device=dl.device)
+        dx[:, 0] = dxc
+        return dx, dg, dbeta, dW0, db0, dW3, db3, None
+
+
+class MeanCrossEntropyFn(Function):
+    """(logits_m [M,B,C], labels) -> (mean logits [B,C], CE loss)."""
+
+    @staticmethod
+    def forward(ctx, logits_m, labels, smoothing):
+        logits, loss, dl = ops.mean_ce(_f32c(logits_m), labels.to(torch.int64).contiguous(), float(smoothing))
+        ctx.save_for_backward(dl)
+        ctx.M = logits_m.shape[0]
+        return logits, loss
+
+    @staticmethod
+    def backward(ctx, dlogits, dloss):
+        (dl,) = ctx.saved_tensors
+        g = dl * dloss
+        if dlogits is not None:
+            g = g + (dlogits / ctx.M).unsqueeze(0)
+        return g, None, None
+
+
+# ------------------------------------------------------------------------------------------
+# fine-grained Functions for the stand-alone module facades (PreNorm / Attention / FeedForward /
+# CrossAttention / Mlp / MultiHeadAttention used outside their parent block)
+# ------------------------------------------------------------------------------------------
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        shape = x.shape
+        x2 = _f32c(x).reshape(-1, shape[-1])
+        y, mu, rs = ops.layernorm_fwd(x2, w, b, eps)
+        ctx.save_for_backward(x2, mu, rs, w)
+        ctx.shape = shape
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mu, rs, w = ctx.saved_tensors
+        d = x2.shape[1]
+        dyb = dy.reshape(-1, d)
+        dyb = dyb if dyb.dtype == torch.bfloat16 else ops.cast_bf16(_f32c(dyb))
+        dg, db = _zeros(d, x2), _zeros(d, x2)
+        dx, _ = ops.layernorm_bwd(dyb.contiguous(), x2, mu, rs, w, dg, db)
+        return dx.reshape(ctx.shape), dg, db, None
+
+
+def _as_bf16_2d(x):
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.dtype == torch.bfloat16:
+        return x2.contiguous()
+    return ops.cast_bf16(_f32c(x2))
+
+
+class LinearFn(Function):
+    """y = x W^T + b; x any float dtype (cast to bf16), y bf16 or fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, out_f32):
+        x2 = _as_bf16_2d(x)
+        w_s = SHADOWS.get(w)
+        y = _linear(x2, w_s, bias=b, out_dtype=torch.float32 if out_f32 else torch.bfloat16)
+        ctx.save_for_backward(x2, w_s)
+        ctx.meta = (x.shape, x.dtype, b is not None)
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w_s = ctx.saved_tensors
+        shape, xdtype, has_b = ctx.meta
+        dyb = _as_bf16_2d(dy)
+        dx = _dgrad(dyb, w_s).reshape(shape)
+        return dx.to(xdtype), _wgrad(dyb, x2), (ops.colsum(dyb) if has_b else None), None
+
+
+class FeedForwardFn(Function):
+    """Linear -> exact GELU -> Linear (model_cross.py:19-31, model.py:107-122), fp32 out."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        x2 = _as_bf16_2d(x)
+        w1_s, w2_s = SHADOWS.get(w1), SHADOWS.get(w2)
+        z = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.bfloat16, device=x.device)
+        a = _linear(x2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z)
+        y = _linear(a, w2_s, bias=b2, out_dtype=torch.float32)
+        ctx.save_for_backward(x2, z, a, w1_s, w2_s)
+        ctx.meta = (x.shape, x.dtype)
+        return y.reshape(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, z, a, w1_s, w2_s = ctx.saved_tensors
+        shape, xdtype = ctx.meta
+        dyb = _as_bf16_2d(dy)
+        dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z)
+        dx = _dgrad(dz, w1_s).reshape(shape)
+        return dx.to(xdtype), _wgrad(dz, x2), ops.colsum(dz), _wgrad(dyb, a), ops.colsum(dyb)
+
+
+class AttentionCoreFn(Function):
+    """softmax(q k^T scale) v on a fused [B, N, 3d] qkv tensor."""
+
+    @staticmethod
+    def forward(ctx, qkv, H, scale):
+        B, N, d3 = qkv.shape
+        q2 = _as_bf16_2d(qkv)
+        o, lse = ops.attn_fwd(q2, B, N, H, scale)
+        ctx.save_for_backward(q2, o, lse)
+        ctx.meta = (B, N, H, scale, qkv.dtype)
+        return o.reshape(B, N, d3 // 3)
+
+    @staticmethod
+    def backward(ctx, do):
+        q2, o, lse = ctx.saved_tensors
+        B, N, H, scale, dt = ctx.meta
+        dqkv = ops.attn_bwd(q2, o, _as_bf16_2d(do), lse, B, N, H, scale)
+        return dqkv.reshape(B, N, -1).to(dt), None, None
+
+
+class ClsAttentionCoreFn(Function):
+    """one CLS query per (b, h) against N keys: q [B, d], kv [B, N, 2d] -> [B, d]."""
+
+    @staticmethod
+    def forward(ctx, q, kv, H, scale):
+        B, N, d2 = kv.shape
+        qb, kvb = _as_bf16_2d(q), _as_bf16_2d(kv)
+        o, p = ops.cls_xattn_fwd(qb, kvb, B, N, H, scale)
+        ctx.save_for_backward(qb, kvb, p)
+        ctx.meta = (B, N, H, scale, q.dtype, kv.dtype)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qb, kvb, p = ctx.saved_tensors
+        B, N, H, scale, qdt, kvdt = ctx.meta
+        dq, dkv = ops.cls_xattn_bwd(qb, kvb, p, _as_bf16_2d(do), B, N, H, scale)
+        return dq.to(qdt), dkv.reshape(B, N, -1).to(kvdt), None, None

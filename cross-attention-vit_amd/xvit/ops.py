@@ -163,14 +163,15 @@ def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale):
     return dq, dkv
 
 
-def patchify(img, patch):
-    """img [B, M, 1, D, H, W] fp32|bf16 contiguous -> patches bf16 [M, B*P, pd]."""
+def patchify(img, patch, pad_cls_row=False):
+    """img [B, M, 1, D, H, W] fp32|bf16 contiguous -> patches bf16 [M, B*(P+pad), pd]."""
     assert img.dim() == 6 and img.shape[2] == 1 and img.is_contiguous()
     B, M, _, D, H, W = img.shape
     dp, hp, wp = patch
     P, pd = (D // dp) * (H // hp) * (W // wp), dp * hp * wp
-    out = torch.empty(M, B * P, pd, dtype=torch.bfloat16, device=img.device)
-    _lib.check(_lib.load().xvit_patchify(_ptr(img), _dt(img), _ptr(out), B, M, D, H, W, dp, hp, wp, _stream()), "xvit_patchify")
+    pad = int(bool(pad_cls_row))
+    out = torch.empty(M, B * (P + pad), pd, dtype=torch.bfloat16, device=img.device)
+    _lib.check(_lib.load().xvit_patchify(_ptr(img), _dt(img), _ptr(out), B, M, D, H, W, dp, hp, wp, pad, _stream()), "xvit_patchify")
     return out
 
 
@@ -215,12 +216,13 @@ def small_linear_fwd(x, W, b):
     return y
 
 
-def small_linear_bwd(dy, x, W, dW, db):
+def small_linear_bwd(dy, x, W, dW, db, z=None):
+    """dx = (dy W) * gelu'(z) if z is given (x = gelu(z))."""
     M, K = x.shape
     N = W.shape[0]
     dx = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.load().xvit_small_linear_bwd(_ptr(dy), _ptr(x), _rows2d(x), _ptr(W), _ptr(dx), K, _ptr(dW), _ptr(db), M, N, K, _stream()),
-               "xvit_small_linear_bwd")
+    _lib.check(_lib.load().xvit_small_linear_bwd(_ptr(dy), _ptr(x), _rows2d(x), _ptr(W), _ptr(z), _rows2d(z) if z is not None else 0,
+                                                 _ptr(dx), K, _ptr(dW), _ptr(db), M, N, K, _stream()), "xvit_small_linear_bwd")
     return dx
 
 

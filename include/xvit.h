@@ -77,9 +77,10 @@ int xvit_gemm(const xvit_gemm_args* args, xvit_stream_t stream);
 /* Tiny fp32 linear for shapes the MFMA tile cannot address (the num_classes=2 head,
  * model_cross.py:181).  y[M,N] = x[M,K] W[N,K]^T + b.  x is bf16, W/b/y fp32.  */
 int xvit_small_linear_fwd(const void* x_bf16, int64_t ldx, const float* W, const float* b, float* y, int M, int N, int K, xvit_stream_t stream);
-/* dx[M,K] (bf16) = dy W;  dW[N,K] += dy^T x;  db[N] += colsum(dy).  dy fp32. */
-int xvit_small_linear_bwd(const float* dy, const void* x_bf16, int64_t ldx, const float* W, void* dx_bf16, int64_t lddx,
-                          float* dW, float* db, int M, int N, int K, xvit_stream_t stream);
+/* dx[M,K] (bf16) = (dy W) * (z ? gelu'(z) : 1);  dW[N,K] += dy^T x;  db[N] += colsum(dy).  dy fp32.
+ * z (bf16 [M,K], optional) is the pre-activation of the GELU that produced x (model_cross.py:178). */
+int xvit_small_linear_bwd(const float* dy, const void* x_bf16, int64_t ldx, const float* W, const void* z_bf16, int64_t ldz,
+                          void* dx_bf16, int64_t lddx, float* dW, float* db, int M, int N, int K, xvit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (model_cross.py:11-17 PreNorm, :174/:203 final norm; model.py:186-187,207 eps=1e-6).
@@ -122,10 +123,12 @@ int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v,
 
 /* ------------------------------------------------------------------------------------------
  * 3-D patchify (model_cross.py:193): img [B, M, 1, D, H, W] (fp32 or bf16, contiguous) ->
- * patches bf16 [M, B, P, pd]; token t = (h*Wn + w)*Dn + d, feature f = (p1*hp + p2)*wp + p3.
+ * patches bf16 [M, B, P + pad, pd]; token t = (h*Wn + w)*Dn + d, feature f = (p1*hp + p2)*wp + p3.
+ * pad_cls_row = 1 leaves an all-zero row 0 in front of every sample's P patch rows, so the patch
+ * matrix lines up row-for-row with the [M*B, N = P+1, d] token tensor (the CLS row, :195-196).
  * ---------------------------------------------------------------------------------------- */
 int xvit_patchify(const void* img, int img_dtype, void* patches_bf16, int B, int M, int D, int H, int W, int dp, int hp, int wp,
-                  xvit_stream_t stream);
+                  int pad_cls_row, xvit_stream_t stream);
 /* x[m, b, 0, :] = cls + pos[0]  (model_cross.py:195-197, the CLS row); x fp32 [M*B, N, d] */
 int xvit_cls_row_fwd(const float* cls, const float* pos, float* x, int MB, int N, int d, xvit_stream_t stream);
 /* dpos[n,:] += sum_{mb} dx[mb,n,:];  dcls += sum_{mb} dx[mb,0,:] */

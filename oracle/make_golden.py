@@ -87,9 +87,7 @@ def to_ref_config(cfg, ConfigDict):
 
 
 # ------------------------------------------------------------------------------ helpers
-def sample_idx(numel: int, k: int, seed: int):
-    g = torch.Generator().manual_seed(seed)
-    return torch.randint(0, numel, (min(k, numel),), generator=g)
+sample_idx = R.sample_idx
 
 
 def rel_err(a, b):

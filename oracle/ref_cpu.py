@@ -174,8 +174,43 @@ def bf16_round(t: torch.Tensor) -> torch.Tensor:
     return t.to(torch.bfloat16).to(t.dtype) if t.is_floating_point() else t
 
 
+def sample_idx(numel: int, k: int, seed: int) -> torch.Tensor:
+    """Deterministic sample positions shared by the fixture writer and the tests."""
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, numel, (min(k, numel),), generator=g)
+
+
 def tensor_sha256(t: torch.Tensor) -> str:
     return hashlib.sha256(t.detach().contiguous().cpu().numpy().tobytes()).hexdigest()
+
+
+# --------------------------------------------------------------------------------------
+# optional emulation of the HIP pipeline's storage precision
+# --------------------------------------------------------------------------------------
+# By default every function below is the exact fp32/fp64 restatement (the form pinned against the
+# reference).  Inside `with emulate_bf16():` operands are additionally rounded to bf16 at exactly
+# the points where the HIP path stores or feeds bf16: both operands of every GEMM, the q/k/v
+# projections' outputs, and the (un-normalised) softmax probabilities fed to the P.V product.
+# Accumulation stays fp32, the residual stream stays fp32 — the arithmetic class of the kernels.
+# GPU-vs-emulation isolates kernel bugs from the (expected) cost of bf16 operands.
+
+_QUANT = None
+
+
+class emulate_bf16:
+    def __enter__(self):
+        global _QUANT
+        self._prev, _QUANT = _QUANT, bf16_round
+        return self
+
+    def __exit__(self, *exc):
+        global _QUANT
+        _QUANT = self._prev
+        return False
+
+
+def _q(t):
+    return t if _QUANT is None else _QUANT(t)
 
 
 # --------------------------------------------------------------------------------------
@@ -205,9 +240,12 @@ def gelu(x):
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
-def linear(x, w, b=None):
-    y = x @ w.transpose(-1, -2)
-    return y if b is None else y + b
+def linear(x, w, b=None, store=False, w_exact=False):
+    """y = x W^T + b.  Emulation mode rounds x and W (unless w_exact: the fp32 class head) and,
+    when `store`, the result (outputs the HIP path keeps in bf16)."""
+    y = _q(x) @ (w if w_exact else _q(w)).transpose(-1, -2)
+    y = y if b is None else y + b
+    return _q(y) if store else y
 
 
 def _split_heads(t, H):
@@ -226,6 +264,8 @@ def softmax_attention(q, k, v, scale):
     m = s.amax(dim=-1, keepdim=True)
     e = torch.exp(s - m)
     z = e.sum(dim=-1, keepdim=True)
+    if _QUANT is not None and q.shape[-2] > 1:   # flash kernel: bf16 P into the MFMA, fp32 row sum
+        return (_q(e) @ v) / z, (m + torch.log(z)).squeeze(-1)
     return (e / z) @ v, (m + torch.log(z)).squeeze(-1)
 
 
@@ -243,7 +283,7 @@ def feed_forward(sd, p, x):
 def self_attention(sd, p, x, H):
     """model_cross.py:50-61: bias-free fused qkv, scale = dh**-0.5, biased out-proj."""
     d = x.shape[-1]
-    qkv = linear(x, sd[p + ".to_qkv.weight"])
+    qkv = linear(x, sd[p + ".to_qkv.weight"], store=True)
     q, k, v = (_split_heads(t, H) for t in qkv.split(d, dim=-1))
     o, _ = softmax_attention(q, k, v, (d // H) ** -0.5)
     return linear(_merge_heads(o), sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
@@ -259,9 +299,9 @@ def self_block(sd, p, x, H):
 def cls_cross_attention(sd, p, x, H):
     """model_cross.py:88-102: the query is row 0 only; keys/values are all N rows."""
     d = x.shape[-1]
-    q = _split_heads(linear(x[:, 0:1], sd[p + ".wq.weight"], sd[p + ".wq.bias"]), H)
-    k = _split_heads(linear(x, sd[p + ".wk.weight"], sd[p + ".wk.bias"]), H)
-    v = _split_heads(linear(x, sd[p + ".wv.weight"], sd[p + ".wv.bias"]), H)
+    q = _split_heads(linear(x[:, 0:1], sd[p + ".wq.weight"], sd[p + ".wq.bias"], store=True), H)
+    k = _split_heads(linear(x, sd[p + ".wk.weight"], sd[p + ".wk.bias"], store=True), H)
+    v = _split_heads(linear(x, sd[p + ".wv.weight"], sd[p + ".wv.bias"], store=True), H)
     o, _ = softmax_attention(q, k, v, (d // H) ** -0.5)
     return linear(_merge_heads(o), sd[p + ".proj.weight"], sd[p + ".proj.bias"])
 
@@ -325,7 +365,7 @@ def model_cross_forward(sd, img, labels, cfg, capture: dict | None = None):
     for m, x in enumerate(xs):
         c = layer_norm(x, sd[f"norm.{m}.weight"], sd[f"norm.{m}.bias"])[:, 0]
         h = gelu(linear(c, sd[f"mlp_head.{m}.0.weight"], sd[f"mlp_head.{m}.0.bias"]))
-        per_mod.append(linear(h, sd[f"mlp_head.{m}.3.weight"], sd[f"mlp_head.{m}.3.bias"]))
+        per_mod.append(linear(h, sd[f"mlp_head.{m}.3.weight"], sd[f"mlp_head.{m}.3.bias"], w_exact=True))
     logits = torch.stack(per_mod).mean(dim=0)
     return logits, cross_entropy(logits, labels, cfg.label_smoothing)
 
@@ -345,9 +385,9 @@ def model_cross_loss_and_grads(sd, img, labels, cfg):
 
 def mha(sd, p, x, H):
     """model.py:156-178."""
-    q = _split_heads(linear(x, sd[p + ".query.weight"], sd[p + ".query.bias"]), H)
-    k = _split_heads(linear(x, sd[p + ".key.weight"], sd[p + ".key.bias"]), H)
-    v = _split_heads(linear(x, sd[p + ".value.weight"], sd[p + ".value.bias"]), H)
+    q = _split_heads(linear(x, sd[p + ".query.weight"], sd[p + ".query.bias"], store=True), H)
+    k = _split_heads(linear(x, sd[p + ".key.weight"], sd[p + ".key.bias"], store=True), H)
+    v = _split_heads(linear(x, sd[p + ".value.weight"], sd[p + ".value.bias"], store=True), H)
     o, _ = softmax_attention(q, k, v, 1.0 / math.sqrt(x.shape[-1] // H))
     return linear(_merge_heads(o), sd[p + ".out.weight"], sd[p + ".out.bias"])
 
