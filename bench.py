@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 3-D patch-tokens/sec, forward + backward, 2-modality 128^3 p16 cross-attention
+ViT (BASELINE.json configs[1]: d=768, 12 heads, mlp 3072, 2x2 blocks, N=513) on N MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = zero-grad, per-step bf16 re-cast of the fp32 master weights (what an optimizer step
+forces in training), forward incl. loss, backward, and for N>1 the complete bucketed gradient
+all-reduce over RCCL (overlapped with backward on a side stream).  Optimizer step and data
+loading are excluded (metric definition).  Inputs are synthetic and already resident
+in HBM; weak scaling (fixed per-GPU batch).  Rank 0 prints ONE JSON line.
+
+Also reported in that line:
+  roofline      the kernel family with the largest share of step time, priced live with HIP events
+                on the launch stream (extra profiled steps after the timed region)
+  kernels       the same pricing for every kernel family (MFMA TFLOP/s or HBM GB/s)
+  cpu_baseline  the CPU oracle (oracle/ref_cpu.py, a port of the reference path) timed on this
+                box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cross-attention-vit_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_PEAK_TF = 2516.0   # bf16 dense, MI355X_MICROARCH.md: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
+HBM_PEAK_GBS = 8000.0   # HBM3E spec
+
+
+def base_config(dropout=0.0):
+    from types import SimpleNamespace
+    return SimpleNamespace(
+        hidden_dim=768, mlp_dim=3072, num_heads=12, num_multi_blocks=2, num_self_blocks=2,
+        img_size=(128, 128, 128), patch_size=(16, 16, 16), num_modalities=2, attn_order={"0": "1", "1": "0"},
+        num_classes=2, dropout=dropout, lr=1e-4, weight_decay=0.0, optim_params={"T_max": 1, "eta_min": 0.0}, label_smoothing=0.0)
+
+
+def flops_per_sample(cfg):
+    """Closed form of BASELINE.md §3 -> (fwd, fwd+bwd) matmul FLOPs per sample."""
+    D, H, W = cfg.img_size
+    dp, hp, wp = cfg.patch_size
+    P = (D // dp) * (H // hp) * (W // wp)
+    N, pd, d, f, M = P + 1, dp * hp * wp, cfg.hidden_dim, cfg.mlp_dim, cfg.num_modalities
+    PE = 2 * M * P * pd * d
+    SAB = 2 * N * d * 3 * d + 2 * (2 * N * N * d) + 2 * N * d * d + 2 * (2 * N * d * f)
+    CAB = 2 * (2 * N * d * d) + 2 * (2 * d * d) + 2 * (2 * N * d) + 2 * (2 * d * f)
+    HEAD = M * (2 * d * f + 2 * f * cfg.num_classes)
+    fwd = PE + cfg.num_multi_blocks * (M * cfg.num_self_blocks * SAB + len(cfg.attn_order) * CAB) + HEAD
+    return fwd, 3 * fwd - PE, P
+
+
+def log(msg):
+    print(f"[bench +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
+def usable_cores():
+    """Cores this process may actually use: min(affinity, cgroup CPU quota, 32)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The oracle (a CPU port of the reference path, oracle/ref_cpu.py) on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu as R
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: {cores} threads (os.cpu_count()={os.cpu_count()})")
+    B = 2
+    sd = R.make_state_dict(cfg, seed=0)
+    img, labels = R.make_inputs(cfg, B, seed=0)
+    _, _, P = flops_per_sample(cfg)
+    times = []
+    t_all = time.perf_counter()
+    for i in range(6):
+        t0 = time.perf_counter()
+        R.model_cross_loss_and_grads(sd, img, labels, cfg)
+        dt = time.perf_counter() - t0
+        log(f"cpu_baseline step {i}: {dt:.2f} s")
+        if i > 0:
+            times.append(dt)
+        if time.perf_counter() - t_all > seconds_budget and len(times) >= 2:
+            break
+    med = statistics.median(times)
+    return {"value": round(B * cfg.num_modalities * P / med, 1), "unit": "patch-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/ref_cpu.py fwd+bwd fp32, same config, batch {B}, median of {len(times)} steps after 1 warm-up ({med * 1e3:.0f} ms/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch of volume pairs")
+    ap.add_argument("--profile-steps", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import xvit
+    from xvit import ops
+    from xvit.ddp import BucketedGradReducer
+
+    cfg = base_config()
+    fwd_f, both_f, P = flops_per_sample(cfg)
+    M, B = cfg.num_modalities, args.batch
+    torch.manual_seed(0)
+    model = xvit.ModelCross(cfg).to(dev)
+    model.train()
+    params = [p for p in model.parameters()]
+    reducer = BucketedGradReducer(params, bucket_bytes=32 << 20) if world > 1 else None
+
+    gen = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn(B, M, 1, *cfg.img_size, generator=gen).to(dev, torch.bfloat16)   # random (not zero) data: MI355X_MICROARCH.md DVFS note
+    labels = torch.randint(0, cfg.num_classes, (B,), generator=gen).to(dev)
+
+    def step():
+        for p in params:
+            p.grad = None
+        xvit.invalidate_shadows()          # weights "changed": pay the fp32 -> bf16 operand cast every step
+        _, loss = model(img, labels)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    log(f"model + inputs ready (B={B}/GPU, world={world})")
+    for i in range(args.warmup):
+        step()
+        if i == 0:
+            torch.cuda.synchronize(dev)
+            log("first step done")
+    fence()
+    log("warm-up done")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    log(f"timed region: {ms:.2f} ms/step")
+    tokens_per_s = world * B * M * P * args.steps / dt
+    loss_val = float(loss.detach())
+
+    out = {
+        "metric": "3D patch-tokens/sec fwd+bwd, 2-modality 128^3 p16 ViT", "value": round(tokens_per_s, 1), "unit": "patch-tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[1]: ModelCross d=768 H=12 mlp=3072 2x2 blocks, 2 modalities, 128^3 volume, 16^3 patches (N=513), dropout 0",
+                   "per_gpu_batch": B, "global_batch": world * B, "seq_len": P + 1, "parallelism": f"dp{world}",
+                   "step": "zero-grad + weight bf16 cast + fwd + loss + bwd" + (" + bucketed grad all-reduce (RCCL, side stream)" if world > 1 else ""),
+                   "optimizer_step": "excluded"},
+        "model_tflops_per_gpu": round(both_f * B / (dt / args.steps) / 1e12, 1),
+        "mfma_frac_of_peak_step": round(both_f * B / (dt / args.steps) / 1e12 / MFMA_PEAK_TF, 4),
+        "loss": round(loss_val, 5),
+    }
+
+    # ---- per-kernel pricing with HIP events on the launch stream (rank 0) --------------------
+    if rank == 0 and args.profile_steps > 0:
+        ops.PROFILE = []
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize(dev)
+        rec, ops.PROFILE = ops.PROFILE, None
+        agg = {}
+        for name, work, kind, s, e in rec:
+            a = agg.setdefault(name, {"kind": kind, "launches": 0, "ms": 0.0, "work": 0.0})
+            a["launches"] += 1
+            a["ms"] += s.elapsed_time(e)
+            a["work"] += work
+        total_ms = sum(a["ms"] for a in agg.values())
+        kernels = {}
+        for name, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+            rate = a["work"] / (a["ms"] * 1e-3)
+            k = {"launches_per_step": a["launches"] // args.profile_steps, "avg_us": round(a["ms"] / a["launches"] * 1e3, 2),
+                 "share_of_kernel_time": round(a["ms"] / total_ms, 4)}
+            if a["kind"] == "flop":
+                k.update(bound="mfma", achieved=round(rate / 1e12, 1), peak=MFMA_PEAK_TF, unit="TFLOP/s", frac=round(rate / 1e12 / MFMA_PEAK_TF, 4))
+            else:
+                k.update(bound="hbm", achieved=round(rate / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(rate / 1e9 / HBM_PEAK_GBS, 4))
+            kernels[name] = k
+        dom = next(iter(kernels))
+        out["roofline"] = {"kernel": dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")},
+                           "avg_launch_us": kernels[dom]["avg_us"], "traffic": None}
+        out["kernels"] = kernels
+        # the north-star's attention target, stated separately
+        if "attn_fwd" in kernels:
+            out["attention_mfma_frac"] = {"fwd": kernels["attn_fwd"]["frac"], "bwd": kernels.get("attn_bwd", {}).get("frac")}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""Data-parallel gradient reduction for the hot path: one process per GPU, batch sharded across
+ranks, ONE exchange step per iteration — the mean of all parameter gradients (SURVEY.md §8(e);
+the reference gets this implicitly from Lightning's DDP, main_mist.py:211-218).
+
+Design for xGMI (point-to-point links, per-link-bound rings): few, large buckets (32 MiB fp32 by
+default -> 12 collectives for the 93 M-parameter config) filled in the order gradients become
+ready during backward (reverse registration order: heads -> last MultiScaleBlock -> ... -> the
+shared patch embedding last).  When the last gradient of a bucket has been accumulated its
+all-reduce is issued immediately on a SIDE stream behind an event, so RCCL traffic overlaps the
+rest of backward; `finish()` makes the compute stream wait for the tail.  After `finish()` every
+`p.grad` is a view into its bucket (no copy back).
+
+The class is device-agnostic (CPU tensors + gloo skip the stream logic), which is what the
+world_size-2 tests in tests/test_ddp_gloo.py run.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    __slots__ = ("params", "flat", "views", "pending", "work", "launched")
+
+    def __init__(self, params, device):
+        self.params = params
+        n = sum(p.numel() for p in params)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self.views, o = [], 0
+        for p in params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+        self.pending, self.work, self.launched = len(params), None, False
+
+
+class BucketedGradReducer:
+    def __init__(self, params, process_group=None, bucket_bytes: int = 32 << 20, broadcast: bool = True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("no parameters to reduce")
+        self.device = params[0].device
+        self.cuda = self.device.type == "cuda"
+        self.comm_stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        if broadcast:  # replicas start identical (DDP does the same at wrap time)
+            for p in params:
+                dist.broadcast(p.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+        # buckets in reverse registration order ~= the order backward produces gradients
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(params):
+            cur.append(p)
+            size += p.numel() * 4
+            if size >= bucket_bytes:
+                self.buckets.append(_Bucket(cur, self.device))
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(_Bucket(cur, self.device))
+        self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
+        self.exposed_launches = 0
+
+    # ---- per-gradient hook (runs inside backward) ----------------------------------------------
+    def _on_grad(self, p):
+        b = self._bucket_of[id(p)]
+        b.pending -= 1
+        if b.pending == 0 and not b.launched:
+            self._launch(b)
+
+    def _launch(self, b):
+        b.launched = True
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
+        scale = 1.0 / self.world
+        if self.cuda:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ready)
+                self._pack(b, grads, scale)
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._pack(b, grads, scale)
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    @staticmethod
+    def _pack(b, grads, scale):
+        srcs = [g for g, v in zip(grads, b.views) if g.data_ptr() != v.data_ptr()]
+        dsts = [v for g, v in zip(grads, b.views) if g.data_ptr() != v.data_ptr()]
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+        b.flat.mul_(scale)
+
+    # ---- after backward ------------------------------------------------------------------------
+    def finish(self):
+        """Wait (stream-side on GPU) for every bucket and point p.grad at the reduced values."""
+        for b in self.buckets:
+            if not b.launched:  # some gradient never arrived (unused parameter): reduce zeros for it
+                self.exposed_launches += 1
+                self._launch(b)
+        for b in self.buckets:
+            b.work.wait()  # NCCL/RCCL: the current stream waits; gloo: the host waits
+            for p, v in zip(b.params, b.views):
+                p.grad = v
+            b.pending, b.work, b.launched = len(b.params), None, False
+
+    def zero_grad(self):
+        """Drop gradients (set_to_none semantics) so the next backward writes fresh tensors."""
+        for b in self.buckets:
+            for p in b.params:
+                p.grad = None
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()

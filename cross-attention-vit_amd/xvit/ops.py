@@ -19,6 +19,23 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional live per-kernel timing (bench.py): when PROFILE is a list, every wrapper brackets its
+# launch with HIP events recorded on the launch stream and appends
+# (kernel family, algorithmic work, "flop" | "byte", start_event, end_event).
+PROFILE = None
+
+
+def _run(name, work, kind, rc_fn, what):
+    if PROFILE is None:
+        _lib.check(rc_fn(), what)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    _lib.check(rc_fn(), what)
+    e.record()
+    PROFILE.append((name, float(work), kind, s, e))
+
+
 def _ptr(t) -> int | None:
     if t is None:
         return None
@@ -82,7 +99,8 @@ def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NON
         a.aux, a.ldaux = _ptr(aux), _rows2d(x2)
         if batched:
             a.stride_aux = aux.stride(0)
-    _lib.check(_lib.load().xvit_gemm(C.byref(a), _stream()), "xvit_gemm")
+    _run(("gemm_nt", "gemm_nn", "gemm_tn")[layout], 2.0 * a.M * a.N * a.K * a.batch, "flop",
+         lambda: _lib.load().xvit_gemm(C.byref(a), _stream()), "xvit_gemm")
     return C_out
 
 
@@ -94,8 +112,9 @@ def layernorm_fwd(x, gamma, beta, eps, *, x_alt=None, seq_len=0, out=None):
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
     if x_alt is not None:
         assert x_alt.shape == x.shape and x_alt.stride() == x.stride()
-    _lib.check(_lib.load().xvit_layernorm_fwd(_ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(gamma), _ptr(beta), eps,
-                                              _ptr(y), _rows2d(y), _ptr(mean), _ptr(rstd), rows, d, _stream()), "xvit_layernorm_fwd")
+    _run("layernorm_fwd", rows * d * 6.0, "byte",
+         lambda: _lib.load().xvit_layernorm_fwd(_ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(gamma), _ptr(beta), eps,
+                                                _ptr(y), _rows2d(y), _ptr(mean), _ptr(rstd), rows, d, _stream()), "xvit_layernorm_fwd")
     return y, mean, rstd
 
 
@@ -104,7 +123,8 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, x_alt=None, seq_le
     rows, d = x.shape
     dx = torch.empty(rows, d, dtype=torch.float32, device=x.device)
     dxb = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
-    _lib.check(_lib.load().xvit_layernorm_bwd(
+    nbytes = rows * d * (2.0 + 4.0 + 4.0 + (4.0 if dres is not None else 0.0) + (2.0 if want_bf16 else 0.0))
+    _run("layernorm_bwd", nbytes, "byte", lambda: _lib.load().xvit_layernorm_bwd(
         _ptr(dy), _rows2d(dy), _ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(mean), _ptr(rstd), _ptr(gamma),
         _ptr(dres), _rows2d(dres) if dres is not None else 0, _ptr(dx), d, _ptr(dxb), d,
         _ptr(dgamma), _ptr(dbeta), rows, d, _stream()), "xvit_layernorm_bwd")
@@ -119,8 +139,9 @@ def attn_fwd(qkv, B, N, H, scale):
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     ld = _rows2d(qkv)
     p = qkv.data_ptr()
-    _lib.check(_lib.load().xvit_attn_fwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), N * d, d, _ptr(lse), B, H, N, dh, scale, _stream()),
-               "xvit_attn_fwd")
+    _run("attn_fwd", 4.0 * B * H * N * N * dh, "flop",
+         lambda: _lib.load().xvit_attn_fwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), N * d, d, _ptr(lse), B, H, N, dh, scale, _stream()),
+         "xvit_attn_fwd")
     return o, lse
 
 
@@ -133,8 +154,9 @@ def attn_bwd(qkv, o, d_o, lse, B, N, H, scale):
     ld = _rows2d(qkv)
     assert dqkv.stride(0) == ld and _rows2d(o) == d and _rows2d(d_o) == d
     p, g = qkv.data_ptr(), dqkv.data_ptr()
-    _lib.check(_lib.load().xvit_attn_bwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), _ptr(d_o), N * d, d, _ptr(lse), _ptr(delta),
-                                         g, g + 2 * d, g + 4 * d, B, H, N, dh, scale, _stream()), "xvit_attn_bwd")
+    _run("attn_bwd", 10.0 * B * H * N * N * dh, "flop",
+         lambda: _lib.load().xvit_attn_bwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), _ptr(d_o), N * d, d, _ptr(lse), _ptr(delta),
+                                           g, g + 2 * d, g + 4 * d, B, H, N, dh, scale, _stream()), "xvit_attn_bwd")
     return dqkv
 
 
@@ -145,8 +167,9 @@ def cls_xattn_fwd(q, kv, B, N, H, scale):
     p = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
     ld = _rows2d(kv)
     kp = kv.data_ptr()
-    _lib.check(_lib.load().xvit_cls_xattn_fwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(o), d, _ptr(p), B, H, N, d // H, scale, _stream()),
-               "xvit_cls_xattn_fwd")
+    _run("cls_xattn_fwd", B * N * 2.0 * d * 2, "byte",
+         lambda: _lib.load().xvit_cls_xattn_fwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(o), d, _ptr(p), B, H, N, d // H, scale, _stream()),
+         "xvit_cls_xattn_fwd")
     return o, p
 
 
@@ -158,8 +181,9 @@ def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale):
     ld = _rows2d(kv)
     assert dkv.stride(0) == ld
     kp, gp = kv.data_ptr(), dkv.data_ptr()
-    _lib.check(_lib.load().xvit_cls_xattn_bwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(p), _ptr(d_o), _rows2d(d_o), _ptr(dq), d,
-                                              gp, gp + 2 * d, B, H, N, d // H, scale, _stream()), "xvit_cls_xattn_bwd")
+    _run("cls_xattn_bwd", B * N * 2.0 * d * 2 * 2, "byte",
+         lambda: _lib.load().xvit_cls_xattn_bwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(p), _ptr(d_o), _rows2d(d_o), _ptr(dq), d,
+                                                gp, gp + 2 * d, B, H, N, d // H, scale, _stream()), "xvit_cls_xattn_bwd")
     return dq, dkv
 
 
@@ -171,7 +195,8 @@ def patchify(img, patch, pad_cls_row=False):
     P, pd = (D // dp) * (H // hp) * (W // wp), dp * hp * wp
     pad = int(bool(pad_cls_row))
     out = torch.empty(M, B * (P + pad), pd, dtype=torch.bfloat16, device=img.device)
-    _lib.check(_lib.load().xvit_patchify(_ptr(img), _dt(img), _ptr(out), B, M, D, H, W, dp, hp, wp, pad, _stream()), "xvit_patchify")
+    _run("patchify", img.numel() * (img.element_size() + 2.0), "byte",
+         lambda: _lib.load().xvit_patchify(_ptr(img), _dt(img), _ptr(out), B, M, D, H, W, dp, hp, wp, pad, _stream()), "xvit_patchify")
     return out
 
 
@@ -180,7 +205,7 @@ def cls_row_fwd(cls, pos, x, MB, N, d):
 
 
 def embed_bwd(dx, dpos, dcls, MB, N, d):
-    _lib.check(_lib.load().xvit_embed_bwd(_ptr(dx), _ptr(dpos), _ptr(dcls), MB, N, d, _stream()), "xvit_embed_bwd")
+    _run("embed_bwd", float(MB) * N * d * 4, "byte", lambda: _lib.load().xvit_embed_bwd(_ptr(dx), _ptr(dpos), _ptr(dcls), MB, N, d, _stream()), "xvit_embed_bwd")
 
 
 def cast_bf16(src, out=None):
@@ -188,7 +213,7 @@ def cast_bf16(src, out=None):
     assert src.dtype == torch.float32 and src.is_contiguous()
     out = out if out is not None else torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
     assert out.is_contiguous() and out.numel() == src.numel()
-    _lib.check(_lib.load().xvit_cast_f32_bf16(_ptr(src), _ptr(out), src.numel(), _stream()), "xvit_cast_f32_bf16")
+    _run("cast_f32_bf16", src.numel() * 6.0, "byte", lambda: _lib.load().xvit_cast_f32_bf16(_ptr(src), _ptr(out), src.numel(), _stream()), "xvit_cast_f32_bf16")
     return out
 
 
@@ -197,7 +222,8 @@ def colsum(x, out=None, accumulate=False):
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=x.device)
         accumulate = False
-    _lib.check(_lib.load().xvit_colsum(_ptr(x), _dt(x), _rows2d(x), _ptr(out), rows, n, int(accumulate), _stream()), "xvit_colsum")
+    _run("colsum", float(rows) * n * x.element_size(), "byte",
+         lambda: _lib.load().xvit_colsum(_ptr(x), _dt(x), _rows2d(x), _ptr(out), rows, n, int(accumulate), _stream()), "xvit_colsum")
     return out
 
 
