@@ -110,9 +110,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch of volume pairs")
+    ap.add_argument("--batch", type=int, default=42, help="per-GPU batch of volume pairs (42*513 rows = 85 row tiles of 256: 85*3 = 255 tiles per d-wide GEMM on 256 CUs)")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail", action="store_true", help="per-shape GEMM table on stderr (diagnostic)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -198,11 +199,21 @@ def main():
 
     # ---- per-kernel pricing with HIP events on the launch stream (rank 0) --------------------
     if rank == 0 and args.profile_steps > 0:
-        ops.PROFILE = []
+        ops.PROFILE, ops.PROFILE_SHAPES = [], args.detail
         for _ in range(args.profile_steps):
             step()
         torch.cuda.synchronize(dev)
         rec, ops.PROFILE = ops.PROFILE, None
+        if args.detail:
+            det = {}
+            for name, work, kind, s, e in rec:
+                d = det.setdefault(name, [0, 0.0, 0.0])
+                d[0] += 1; d[1] += s.elapsed_time(e); d[2] += work
+            for name, (n, ms_, w) in sorted(det.items(), key=lambda kv: -kv[1][1]):
+                unit = "TF/s" if name.startswith(("gemm", "attn")) else "GB/s"
+                rate = w / (ms_ * 1e-3) / (1e12 if unit == "TF/s" else 1e9)
+                print(f"  {name:58s} x{n // args.profile_steps:3d} {ms_ / n * 1e3:9.1f} us  {rate:8.1f} {unit}  total {ms_ / args.profile_steps:7.3f} ms/step", file=sys.stderr)
+            rec = [(n.split("[")[0], w, k, s, e) for n, w, k, s, e in rec]
         agg = {}
         for name, work, kind, s, e in rec:
             a = agg.setdefault(name, {"kind": kind, "launches": 0, "ms": 0.0, "work": 0.0})

@@ -20,7 +20,49 @@ struct GemmParams {
   int M, N, K, k_per_split, split_k, ntm, ntn;
   int c_f32, act, accumulate;
   int res_row_mod, res_row_off, seg_rows, seg_skip, row_off;
+  float* slab;          // split-K partial sums [split][batch][M][N], else nullptr
+  float* colsum;        // optional [N] fp32: += column sums of the stored C
 };
+
+// ---- the fused epilogue, shared by both tile kernels and the split-K reduce kernel -------------
+// v: 4 consecutive output columns of one row (fp32 accumulators).  Returns the value stored.
+template <int ACT>
+__device__ __forceinline__ f32x4 epilogue_apply(const GemmParams& p, f32x4 v, int row, int col, int64_t cb, const float* bias, const float* res,
+                                                bf16* aux) {
+  if (bias) v += *(const f32x4*)(bias + col);
+  if (ACT == XVIT_ACT_GELU) {
+    if (aux) {
+      bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      *(bf16x4*)(aux + (int64_t)row * p.ldaux + col) = z;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
+  } else if (ACT == XVIT_ACT_DGELU) {
+    const bf16x4 z = *(const bf16x4*)(aux + (int64_t)row * p.ldaux + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(bf2f(z[e]));
+  }
+  if (res) {
+    const int rr = p.res_row_mod > 0 ? p.res_row_off + (row % p.res_row_mod) : row;
+    v += *(const f32x4*)(res + (int64_t)rr * p.ldr + col);
+  }
+  const int64_t orow = p.seg_rows > 0 ? (int64_t)row + (row / p.seg_rows) * p.seg_skip + p.row_off : row;
+  if (p.c_f32) {
+    float* dst = (float*)p.C + cb + orow * p.ldc + col;
+    if (p.accumulate) v += *(const f32x4*)dst;
+    *(f32x4*)dst = v;
+  } else {
+    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    *(bf16x4*)((bf16*)p.C + cb + orow * p.ldc + col) = o;
+  }
+  return v;
+}
+__device__ __forceinline__ f32x4 epilogue_apply_rt(const GemmParams& p, f32x4 v, int row, int col, int64_t cb, const float* bias, const float* res,
+                                                   bf16* aux) {
+  if (p.act == XVIT_ACT_GELU) return epilogue_apply<XVIT_ACT_GELU>(p, v, row, col, cb, bias, res, aux);
+  if (p.act == XVIT_ACT_DGELU) return epilogue_apply<XVIT_ACT_DGELU>(p, v, row, col, cb, bias, res, aux);
+  return epilogue_apply<XVIT_ACT_NONE>(p, v, row, col, cb, bias, res, aux);
+}
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int OPER_BYTES = BM * BK * 2;        // 16 KiB per operand per stage
@@ -115,9 +157,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int k_begin = split * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin + BK - 1) / BK;
-  if (nk <= 0) return;
-
-  OperandLoader<A_KS> la;
+  OperandLoader<A_KS> la;   // nk may be 0 for a trailing split: it still writes its (zero) partial tile
   OperandLoader<B_KS> lb;
   {
     const bf16* Ab = p.A + batch * p.sA;
@@ -148,8 +188,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  la.issue(smem, wave, 0);
-  lb.issue(smem + OPER_BYTES, wave, 0);
+  if (nk > 0) {
+    la.issue(smem, wave, 0);
+    lb.issue(smem + OPER_BYTES, wave, 0);
+  }
 
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -182,7 +224,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const float* bias = p.bias ? p.bias + batch * p.sBias : nullptr;
   const float* res = p.res ? p.res + batch * p.sR : nullptr;
   bf16* aux = p.aux ? p.aux + batch * p.sAux : nullptr;
-  const bool atomic = p.split_k > 1;
+  float* csum = p.colsum ? p.colsum + batch * p.sBias : nullptr;
+  const int nbatch = gridDim.z / p.split_k;
+  float* part = p.slab ? p.slab + ((int64_t)split * nbatch + batch) * (int64_t)p.M * p.N : nullptr;
 
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
@@ -194,53 +238,247 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         for (int r = 0; r < 4; ++r)
           slab[(mi * 16 + (lane >> 4) * 4 + r) * EPI_LD + j * 16 + (lane & 15)] = acc[pass * 2 + mi][j][r];
     const int row_base = m0 + wr * 64 + pass * 32;
-    const int col_base = n0 + wc * 64;
-    if (atomic) {
-      // 256 contiguous bytes per wave-instruction: the shape float atomics run fastest at
-      const int col = col_base + lane;
-      float* C = (float*)p.C + cb;
-#pragma unroll 4
-      for (int r = 0; r < 32; ++r) {
-        const int row = row_base + r;
-        const float v = slab[r * EPI_LD + lane];
-        if (row < p.M && col < p.N) unsafeAtomicAdd(C + (int64_t)row * p.ldc + col, v);
-      }
-    } else {
+    const int col = n0 + wc * 64 + (lane & 15) * 4;
 #pragma unroll 1
-      for (int it = 0; it < 8; ++it) {
-        const int rl = it * 4 + (lane >> 4);
-        const int row = row_base + rl;
-        const int col = col_base + (lane & 15) * 4;
-        f32x4 v = *(const XVIT_LDS f32x4*)(slab + rl * EPI_LD + (lane & 15) * 4);
-        if (row < p.M && col < p.N) {
-          if (bias) v += *(const f32x4*)(bias + col);
-          if (p.act == XVIT_ACT_GELU) {
-            if (aux) {
-              bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-              *(bf16x4*)(aux + (int64_t)row * p.ldaux + col) = z;
-            }
+    for (int it = 0; it < 8; ++it) {
+      const int rl = it * 4 + (lane >> 4);
+      const int row = row_base + rl;
+      const f32x4 v = *(const XVIT_LDS f32x4*)(slab + rl * EPI_LD + (lane & 15) * 4);
+      if (row < p.M && col < p.N) {
+        if (part) {
+          *(f32x4*)(part + (int64_t)row * p.N + col) = v;   // split-K partial: epilogue runs in the reduce kernel
+        } else {
+          const f32x4 o = epilogue_apply_rt(p, v, row, col, cb, bias, res, aux);
+          if (csum) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-          } else if (p.act == XVIT_ACT_DGELU) {
-            const bf16x4 z = *(const bf16x4*)(aux + (int64_t)row * p.ldaux + col);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(bf2f(z[e]));
-          }
-          if (res) {
-            const int rr = p.res_row_mod > 0 ? p.res_row_off + (row % p.res_row_mod) : row;
-            v += *(const f32x4*)(res + (int64_t)rr * p.ldr + col);
-          }
-          const int64_t orow = p.seg_rows > 0 ? (int64_t)row + (row / p.seg_rows) * p.seg_skip + p.row_off : row;
-          if (p.c_f32) {
-            float* dst = (float*)p.C + cb + orow * p.ldc + col;
-            if (p.accumulate) v += *(const f32x4*)dst;
-            *(f32x4*)dst = v;
-          } else {
-            bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-            *(bf16x4*)((bf16*)p.C + cb + orow * p.ldc + col) = o;
+            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(csum + col + e, o[e]);
           }
         }
       }
+    }
+  }
+}
+
+// ==========================================================================================
+// Big-tile kernel: 256x256x64 block tile, 512 threads = 8 waves (2 along M x 4 along N), each wave
+// 128x64 = 8x4 tiles of v_mfma_f32_16x16x32_bf16 (128 accumulator registers).  128 FLOP per byte
+// staged into LDS (the 128^2 tile's 64 FLOP/B is bound by the L2->LDS rate, not by MFMA).  One
+// block per CU (128 KiB LDS, 2 stages).  The MFMA operand roles are swapped (weights as "A",
+// activations as "B"), so a lane's 4 accumulator registers are 4 CONSECUTIVE output columns of one
+// row: the epilogue runs straight from registers with 8/16-byte stores — no LDS round trip.
+// Split-K writes fp32 partial tiles to a slab (plain stores); splitk_reduce_kernel sums them in a
+// fixed order (bit-reproducible, no atomics).
+// ==========================================================================================
+constexpr int TBM = 256, TBN = 256;
+constexpr int T_OPER = TBM * BK * 2;     // 32 KiB per operand per stage
+constexpr int T_STAGE = 2 * T_OPER;      // 64 KiB
+constexpr int T_LDS = 2 * T_STAGE;       // 128 KiB
+
+template <bool KS>
+struct BigLoader {
+  __amdgpu_buffer_rsrc_t rsrc;
+  uint32_t voff[4];
+  uint32_t kstep;
+  // 32 KiB image = 32 pieces of 1 KiB; wave w moves pieces 4w .. 4w+3
+  __device__ __forceinline__ void init(const bf16* tile_base, int64_t bytes_avail, int64_t ld, int wave, int lane) {
+    rsrc = make_rsrc(tile_base, clamp_bytes(bytes_avail));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int piece = wave * 4 + j;
+      if (KS) {  // image [64 k][256 cols], 512-B rows: a piece is 2 k-rows
+        const int krow = piece * 2 + (lane >> 5);
+        const int chunk = (lane & 31) ^ swz_ks(krow);
+        voff[j] = (uint32_t)(krow * ld * 2 + chunk * 16);
+      } else {   // image [256 rows][64 k], 128-B rows: a piece is 8 rows
+        const int row = piece * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz_kc(row);
+        voff[j] = (uint32_t)(row * ld * 2 + chunk * 16);
+      }
+    }
+    kstep = KS ? (uint32_t)(BK * ld * 2) : (uint32_t)(BK * 2);
+  }
+  __device__ __forceinline__ void issue(XVIT_LDS char* image, int wave, int kt) const {
+    const uint32_t soff = (uint32_t)kt * kstep;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) glds16(rsrc, image + (wave * 4 + j) * 1024, voff[j], soff);
+  }
+};
+
+// NT = number of 16-wide tiles this wave reads from the image (8 along M, 4 along N);
+// `first` = index of the wave's first 16-wide tile inside the 256-wide image.
+template <bool KS, int NT_>
+struct BigFrag {
+  uint32_t off[KS ? 2 * NT_ : 2];
+  __device__ __forceinline__ void init(int first, int lane) {
+    if (KS) {
+      const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+#pragma unroll
+      for (int t = 0; t < NT_; ++t)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const int krow = 8 * g + 4 * s + q;
+          const int ch = (first + t) * 2 + (p >> 1);
+          off[t * 2 + s] = (uint32_t)(512 * krow + 16 * (ch ^ swz_ks(krow)) + 8 * (p & 1));
+        }
+    } else {
+      const int row = first * 16 + (lane & 15);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) off[kk] = (uint32_t)(row * 128 + (((kk * 4 + (lane >> 4)) ^ swz_kc(row)) << 4));
+    }
+  }
+  __device__ __forceinline__ bf16x8 read(const XVIT_LDS char* image, int t, int kk) const {
+    if (KS) {
+      const s16x4 lo = lds_read_tr16(image + off[t * 2 + 0] + kk * 32 * 512);
+      const s16x4 hi = lds_read_tr16(image + off[t * 2 + 1] + kk * 32 * 512);
+      s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    } else {
+      return *(const XVIT_LDS bf16x8*)(image + off[kk] + t * 16 * 128);
+    }
+  }
+};
+
+struct BigEpi {
+  int64_t cb;
+  const float* bias; const float* res; bf16* aux; float* slab_tile; float* colsum;
+  int row0, col0;
+};
+
+template <int ACT, int I, int J>
+__device__ __forceinline__ void big_epi_one(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4], f32x4 (&cs)[4]) {
+  const int row = e.row0 + I * 16, col = e.col0 + J * 16;
+  if (row < p.M && col < p.N) {
+    if (e.slab_tile) *(f32x4*)(e.slab_tile + (int64_t)row * p.N + col) = acc[I][J];   // split-K partial sums
+    else cs[J] += epilogue_apply<ACT>(p, acc[I][J], row, col, e.cb, e.bias, e.res, e.aux);
+  }
+}
+template <int ACT, int I>
+__device__ __forceinline__ void big_epi_row(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4], f32x4 (&cs)[4]) {
+  big_epi_one<ACT, I, 0>(p, e, acc, cs); big_epi_one<ACT, I, 1>(p, e, acc, cs); big_epi_one<ACT, I, 2>(p, e, acc, cs); big_epi_one<ACT, I, 3>(p, e, acc, cs);
+}
+template <int ACT>
+__device__ __forceinline__ void big_epilogue(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4], int lane) {
+  f32x4 cs[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  big_epi_row<ACT, 0>(p, e, acc, cs); big_epi_row<ACT, 1>(p, e, acc, cs); big_epi_row<ACT, 2>(p, e, acc, cs); big_epi_row<ACT, 3>(p, e, acc, cs);
+  big_epi_row<ACT, 4>(p, e, acc, cs); big_epi_row<ACT, 5>(p, e, acc, cs); big_epi_row<ACT, 6>(p, e, acc, cs); big_epi_row<ACT, 7>(p, e, acc, cs);
+  if (e.colsum) {  // this wave's 128 rows: 8 in-lane + the 16 lanes that share (lane >> 4); one atomic per column per wave
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float v = cs[j][c];
+        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+        const int col = e.col0 + j * 16 + c;
+        if ((lane & 15) == 0 && col < p.N) unsafeAtomicAdd(e.colsum + col, v);
+      }
+  }
+}
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;   // 2 x 4 waves
+
+  const int nblk = gridDim.x, bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tm = logical / p.ntn, tn = logical - tm * p.ntn;
+  const int m0 = tm * TBM, n0 = tn * TBN;
+  const int batch = blockIdx.z / p.split_k, split = blockIdx.z - batch * p.split_k;
+  const int k_begin = split * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int nk = (k_end - k_begin + BK - 1) / BK;   // may be 0 for a trailing split: still writes its (zero) slab
+
+  BigLoader<A_KS> la;
+  BigLoader<B_KS> lb;
+  {
+    const bf16* Ab = p.A + batch * p.sA;
+    if (A_KS) la.init(Ab + (int64_t)k_begin * p.lda + m0, ((int64_t)(k_end - 1 - k_begin) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane);
+    else la.init(Ab + (int64_t)m0 * p.lda + k_begin, ((int64_t)(p.M - 1 - m0) * p.lda + (k_end - k_begin)) * 2, p.lda, wave, lane);
+    const bf16* Bb = p.B + batch * p.sB;
+    if (B_KS) lb.init(Bb + (int64_t)k_begin * p.ldb + n0, ((int64_t)(k_end - 1 - k_begin) * p.ldb + (p.N - n0)) * 2, p.ldb, wave, lane);
+    else lb.init(Bb + (int64_t)n0 * p.ldb + k_begin, ((int64_t)(p.N - 1 - n0) * p.ldb + (k_end - k_begin)) * 2, p.ldb, wave, lane);
+  }
+  BigFrag<A_KS, 8> fa;
+  BigFrag<B_KS, 4> fb;
+  fa.init(wr * 8, lane);
+  fb.init(wc * 4, lane);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (nk > 0) {
+    la.issue(smem, wave, 0);
+    lb.issue(smem + T_OPER, wave, 0);
+  }
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) {
+      XVIT_LDS char* nxt = smem + ((kt + 1) & 1) * T_STAGE;
+      la.issue(nxt, wave, kt + 1);
+      lb.issue(nxt + T_OPER, wave, kt + 1);
+    }
+    const XVIT_LDS char* sa = smem + (kt & 1) * T_STAGE;
+    const XVIT_LDS char* sb = sa + T_OPER;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 bfr[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bfr[t] = fb.read(sb, t, kk);
+#pragma unroll
+      for (int mh = 0; mh < 2; ++mh) {
+        bf16x8 af[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) af[t] = fa.read(sa, mh * 4 + t, kk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);  // D'[n][m]
+      }
+    }
+  }
+
+  // ---------------- epilogue straight from the accumulators ------------------------------------
+  BigEpi e;
+  e.cb = batch * p.sC;
+  e.bias = p.bias ? p.bias + batch * p.sBias : nullptr;
+  e.res = p.res ? p.res + batch * p.sR : nullptr;
+  e.aux = p.aux ? p.aux + batch * p.sAux : nullptr;
+  const int nbatch = gridDim.z / p.split_k;
+  e.slab_tile = p.slab ? p.slab + ((int64_t)split * nbatch + batch) * (int64_t)p.M * p.N : nullptr;
+  e.colsum = (p.colsum && !p.slab) ? p.colsum + batch * p.sBias : nullptr;
+  e.row0 = m0 + wr * 128 + (lane & 15);
+  e.col0 = n0 + wc * 64 + (lane >> 4) * 4;
+  // one specialised, fully unrolled copy per activation: every acc[][] index is a compile-time constant
+  if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU>(p, e, acc, lane);
+  else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU>(p, e, acc, lane);
+  else big_epilogue<XVIT_ACT_NONE>(p, e, acc, lane);
+}
+
+// split-K second pass: sum the partial tiles in a fixed order (bit-reproducible), then the full epilogue
+__global__ void splitk_epilogue_kernel(const GemmParams p, int nbatch) {
+  const int nv = p.N >> 2;
+  const int64_t per = (int64_t)p.M * nv, total = per * nbatch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    const int64_t r = i - (int64_t)b * per;
+    const int row = (int)(r / nv), col = (int)(r - (int64_t)row * nv) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < p.split_k; ++s) v += *(const f32x4*)(p.slab + (((int64_t)s * nbatch + b) * p.M + row) * p.N + col);
+    const f32x4 o = epilogue_apply_rt(p, v, row, col, b * p.sC, p.bias ? p.bias + b * p.sBias : nullptr, p.res ? p.res + b * p.sR : nullptr,
+                                      p.aux ? p.aux + b * p.sAux : nullptr);
+    if (p.colsum) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) unsafeAtomicAdd(p.colsum + b * p.sBias + col + e, o[e]);
     }
   }
 }
@@ -250,6 +488,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 using namespace xvit;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static bool use_big_tile(const xvit_gemm_args* a) { return a->M >= 256 && a->N >= 256; }
+
+extern "C" int64_t xvit_gemm_workspace_bytes(const xvit_gemm_args* a) {
+  if (!a || a->split_k <= 1) return 0;
+  return (int64_t)a->split_k * a->batch * a->M * a->N * (int64_t)sizeof(float);
+}
 
 extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   XVIT_REQUIRE(a != nullptr, "xvit_gemm: null args");
@@ -267,13 +512,17 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   const int64_t a_rows = a_ks ? a->K : a->M, b_rows = b_ks ? a->K : a->N;
   XVIT_REQUIRE(a_rows * a->lda * 2 < (1ll << 31) && b_rows * a->ldb * 2 < (1ll << 31), "xvit_gemm: an operand matrix exceeds 2 GiB (unsupported addressing range)");
   XVIT_REQUIRE(a->split_k >= 1, "xvit_gemm: split_k must be >= 1");
-  if (a->split_k > 1)
-    XVIT_REQUIRE(a->c_dtype == XVIT_F32 && a->act == XVIT_ACT_NONE && !a->bias && !a->residual && a->out_seg_rows == 0, "xvit_gemm: split_k > 1 needs a plain fp32 accumulate epilogue");
   XVIT_REQUIRE(!(a->accumulate && a->c_dtype != XVIT_F32), "xvit_gemm: accumulate needs fp32 C");
   XVIT_REQUIRE(a->act != XVIT_ACT_DGELU || a->aux, "xvit_gemm: ACT_DGELU needs aux (pre-activation)");
   if (a->aux) XVIT_REQUIRE(a->ldaux % 4 == 0 && a->ldaux >= a->N && (reinterpret_cast<uintptr_t>(a->aux) & 7) == 0, "xvit_gemm: bad aux layout");
   if (a->residual) XVIT_REQUIRE(a->ldr % 4 == 0 && a->ldr >= a->N && aligned16(a->residual), "xvit_gemm: bad residual layout");
   if (a->bias) XVIT_REQUIRE(aligned16(a->bias) && a->stride_bias % 4 == 0, "xvit_gemm: bias must be 16-byte aligned");
+  XVIT_REQUIRE((int64_t)a->batch * a->split_k <= 65535, "xvit_gemm: batch*split_k too large");
+  const bool big = use_big_tile(a);
+  const int64_t ws_need = xvit_gemm_workspace_bytes(a);
+  if (ws_need > 0)
+    XVIT_REQUIRE(a->workspace && a->workspace_bytes >= ws_need && aligned16(a->workspace), "xvit_gemm: split_k=%d needs %lld bytes of 16-byte aligned workspace (got %lld)",
+                 a->split_k, (long long)ws_need, (long long)a->workspace_bytes);
 
   GemmParams p;
   p.A = (const bf16*)a->A; p.B = (const bf16*)a->B; p.C = a->C; p.bias = a->bias; p.res = a->residual; p.aux = (bf16*)a->aux;
@@ -282,25 +531,44 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   p.M = a->M; p.N = a->N; p.K = a->K; p.split_k = a->split_k;
   const int ktiles = (a->K + BK - 1) / BK;
   p.k_per_split = ((ktiles + a->split_k - 1) / a->split_k) * BK;
-  p.ntm = (a->M + BM - 1) / BM; p.ntn = (a->N + BN - 1) / BN;
   p.c_f32 = a->c_dtype == XVIT_F32; p.act = a->act; p.accumulate = a->accumulate;
   p.res_row_mod = a->res_row_mod; p.res_row_off = a->res_row_off;
   p.seg_rows = a->out_seg_rows; p.seg_skip = a->out_seg_skip; p.row_off = a->out_row_off;
-
-  const dim3 grid(p.ntm * p.ntn, 1, a->batch * a->split_k), block(256);
-  XVIT_REQUIRE((int64_t)a->batch * a->split_k <= 65535, "xvit_gemm: batch*split_k too large");
+  p.slab = ws_need > 0 ? (float*)a->workspace : nullptr;
+  p.colsum = a->colsum;
   hipStream_t s = (hipStream_t)stream;
+
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
     attr_done = true;
   }
-  switch (a->layout) {
-    case XVIT_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, GEMM_LDS, s, p); break;
-    case XVIT_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, GEMM_LDS, s, p); break;
-    default: hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, GEMM_LDS, s, p); break;
+  if (big) {
+    p.ntm = (a->M + TBM - 1) / TBM; p.ntn = (a->N + TBN - 1) / TBN;
+    const dim3 grid(p.ntm * p.ntn, 1, a->batch * a->split_k), block(512);
+    switch (a->layout) {
+      case XVIT_GEMM_NT: hipLaunchKernelGGL((gemm_big_kernel<false, false>), grid, block, T_LDS, s, p); break;
+      case XVIT_GEMM_NN: hipLaunchKernelGGL((gemm_big_kernel<false, true>), grid, block, T_LDS, s, p); break;
+      default: hipLaunchKernelGGL((gemm_big_kernel<true, true>), grid, block, T_LDS, s, p); break;
+    }
+  } else {
+    p.ntm = (a->M + BM - 1) / BM; p.ntn = (a->N + BN - 1) / BN;
+    const dim3 grid(p.ntm * p.ntn, 1, a->batch * a->split_k), block(256);
+    switch (a->layout) {
+      case XVIT_GEMM_NT: hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, GEMM_LDS, s, p); break;
+      case XVIT_GEMM_NN: hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, GEMM_LDS, s, p); break;
+      default: hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, GEMM_LDS, s, p); break;
+    }
+  }
+  if (p.slab) {
+    const int64_t work = (int64_t)a->batch * a->M * (a->N / 4);
+    const int g = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(g), dim3(256), 0, s, p, a->batch);
   }
   return check_launch("xvit_gemm");
 }

@@ -61,19 +61,22 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const bf16* __res
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ dres, int64_t lddres,
                                                                float* __restrict__ dx, int64_t lddx, bf16* __restrict__ dxb, int64_t lddxb,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int d) {
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum,
+                                                               float* __restrict__ dressum, int rows, int d) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* red = (float*)smem_raw;  // [LN_WAVES][2][d]
+  float* red = (float*)smem_raw;  // [LN_WAVES][4][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d >> 2;
   const float inv_d = 1.0f / (float)d;
-  f32x4 g[V], dg[V], db[V];
+  f32x4 g[V], dg[V], db[V], sx[V], sr[V];   // sx/sr: column sums of dx and dres (bias gradients of the adjacent Linears)
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     const int c = lane + i * 64;
     g[i] = c < nv ? ((const f32x4*)gamma)[c] : f32x4{0.f, 0.f, 0.f, 0.f};
     dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    sx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    sr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
     const float* src = (x_alt && (row % seq_len) == 0) ? x_alt : x;
@@ -111,7 +114,12 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const bf16* __res
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - m1 - xh[i][e] * m2);
-        if (dres) o += *(const f32x4*)(dres + (int64_t)row * lddres + c * 4);
+        if (dres) {
+          const f32x4 rv = *(const f32x4*)(dres + (int64_t)row * lddres + c * 4);
+          o += rv;
+          sr[i] += rv;
+        }
+        sx[i] += o;
         *(f32x4*)(dx + (int64_t)row * lddx + c * 4) = o;
         if (dxb) {
           bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
@@ -125,17 +133,23 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const bf16* __res
   for (int i = 0; i < V; ++i) {
     const int c = lane + i * 64;
     if (c < nv) {
-      *(f32x4*)(red + (wave * 2 + 0) * d + c * 4) = dg[i];
-      *(f32x4*)(red + (wave * 2 + 1) * d + c * 4) = db[i];
+      *(f32x4*)(red + (wave * 4 + 0) * d + c * 4) = dg[i];
+      *(f32x4*)(red + (wave * 4 + 1) * d + c * 4) = db[i];
+      *(f32x4*)(red + (wave * 4 + 2) * d + c * 4) = sx[i];
+      *(f32x4*)(red + (wave * 4 + 3) * d + c * 4) = sr[i];
     }
   }
   __syncthreads();
   for (int c = threadIdx.x; c < d; c += blockDim.x) {
-    float a = 0.f, b = 0.f;
+    float a = 0.f, b = 0.f, x2 = 0.f, r2 = 0.f;
 #pragma unroll
-    for (int w = 0; w < LN_WAVES; ++w) { a += red[(w * 2 + 0) * d + c]; b += red[(w * 2 + 1) * d + c]; }
+    for (int w = 0; w < LN_WAVES; ++w) {
+      a += red[(w * 4 + 0) * d + c]; b += red[(w * 4 + 1) * d + c]; x2 += red[(w * 4 + 2) * d + c]; r2 += red[(w * 4 + 3) * d + c];
+    }
     unsafeAtomicAdd(dgamma + c, a);
     unsafeAtomicAdd(dbeta + c, b);
+    if (dxsum) unsafeAtomicAdd(dxsum + c, x2);
+    if (dressum) unsafeAtomicAdd(dressum + c, r2);
   }
 }
 
@@ -164,23 +178,24 @@ extern "C" int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ld
 
 extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len,
                                   const float* mean, const float* rstd, const float* gamma, const float* dres, int64_t lddres, float* dx,
-                                  int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, int rows, int d,
-                                  xvit_stream_t stream) {
+                                  int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, float* dxsum, float* dressum, int rows,
+                                  int d, xvit_stream_t stream) {
   XVIT_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "xvit_layernorm_bwd: null pointer");
   XVIT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 4096, "xvit_layernorm_bwd: need 0 < d <= 4096, d %% 4 == 0 (d=%d rows=%d)", d, rows);
   XVIT_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0) && (!dxb || lddxb % 4 == 0),
                "xvit_layernorm_bwd: leading dimensions must be multiples of 4");
   XVIT_REQUIRE(!x_alt || seq_len > 0, "xvit_layernorm_bwd: x_alt needs seq_len > 0");
+  XVIT_REQUIRE(!dressum || dres, "xvit_layernorm_bwd: dressum needs dres");
   hipStream_t s = (hipStream_t)stream;
   int g = ln_grid(rows);
-  if (g > 512) g = 512;  // fewer, longer-lived blocks: fewer dgamma/dbeta atomics
+  if (g > 512) g = 512;  // every block adds its dgamma/dbeta partials to the SAME d addresses: more blocks = atomic contention (measured slower)
   const dim3 grid(g), block(LN_WAVES * 64);
-  const size_t lds = (size_t)LN_WAVES * 2 * d * sizeof(float);
+  const size_t lds = (size_t)LN_WAVES * 4 * d * sizeof(float);
   const bf16* dyb = (const bf16*)dy;
   bf16* dxbb = (bf16*)dxb;
   if (d <= 1024)
-    hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, rows, d);
+    hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, rows, d);
   else
-    hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, rows, d);
+    hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, rows, d);
   return check_launch("xvit_layernorm_bwd");
 }

@@ -85,27 +85,39 @@ __global__ void cast_kernel(const float* __restrict__ src, bf16* __restrict__ ds
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nv << 3) + threadIdx.x] = f2bf(src[(nv << 3) + threadIdx.x]);
 }
 
-// column sums: block = 64 column-quads (256 columns) x 4 row lanes; rows strided by gridDim.y*4
+// column sums: block = 64 column-quads (256 columns) x 4 row lanes over a contiguous slab of rows;
+// 4 independent 16-B loads in flight per thread; one atomic per column per block
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out, int rows, int n) {
+__device__ __forceinline__ f32x4 ld4(const T* p) {
+  if constexpr (sizeof(T) == 4) {
+    return *(const f32x4*)p;
+  } else {
+    const bf16x4 v = *(const bf16x4*)p;
+    return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out, int rows, int n, int rows_per_block) {
   __shared__ f32x4 red[4][64];
   const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + cq) * 4;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int r_begin = blockIdx.y * rows_per_block, r_end = min(rows, r_begin + rows_per_block);
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
   if (col < n) {
-    for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) {
-      if constexpr (sizeof(T) == 4) {
-        acc += *(const f32x4*)(x + (int64_t)r * ldx + col);
-      } else {
-        const bf16x4 v = *(const bf16x4*)(x + (int64_t)r * ldx + col);
-        acc += f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
-      }
+    const T* base = x + col;
+    int r = r_begin + rl;
+    for (; r + 12 < r_end; r += 16) {
+      a0 += ld4(base + (int64_t)r * ldx);
+      a1 += ld4(base + (int64_t)(r + 4) * ldx);
+      a2 += ld4(base + (int64_t)(r + 8) * ldx);
+      a3 += ld4(base + (int64_t)(r + 12) * ldx);
     }
+    for (; r < r_end; r += 4) a0 += ld4(base + (int64_t)r * ldx);
   }
-  red[rl][cq] = acc;
+  red[rl][cq] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (rl == 0 && col < n) {
-    acc = red[0][cq] + red[1][cq] + red[2][cq] + red[3][cq];
+    const f32x4 acc = red[0][cq] + red[1][cq] + red[2][cq] + red[3][cq];
 #pragma unroll
     for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out + col + e, acc[e]);
   }
@@ -260,11 +272,12 @@ extern "C" int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, 
     const hipError_t e = hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s);
     if (e != hipSuccess) { set_error("xvit_colsum: memset failed: %s", hipGetErrorString(e)); return (int)e; }
   }
-  int gy = (rows + 255) / 256;
-  if (gy > 64) gy = 64;
-  const dim3 grid((n / 4 + 63) / 64, gy), block(256);
-  if (x_dtype == XVIT_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, ldx, out, rows, n);
-  else hipLaunchKernelGGL((colsum_kernel<bf16>), grid, block, 0, s, (const bf16*)x, ldx, out, rows, n);
+  const int gx = (n / 4 + 63) / 64;
+  int rpb = 64;                                   // rows per block: >= 64, and at most ~2048 blocks in all
+  while ((int64_t)gx * ((rows + rpb - 1) / rpb) > 2048) rpb *= 2;
+  const dim3 grid(gx, (rows + rpb - 1) / rpb), block(256);
+  if (x_dtype == XVIT_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, ldx, out, rows, n, rpb);
+  else hipLaunchKernelGGL((colsum_kernel<bf16>), grid, block, 0, s, (const bf16*)x, ldx, out, rows, n, rpb);
   return check_launch("xvit_colsum");
 }
 

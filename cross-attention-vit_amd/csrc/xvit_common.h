@@ -72,12 +72,32 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// exact (erf) GELU and its derivative, fp32
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// Exact-form (erf) GELU and its derivative in fp32.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
+// i.e. fp32 round-off level; libm erff costs ~4x the VALU work and the epilogue is VALU-bound):
+//   erf(u) = 1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) e^{-u^2},  t = 1 / (1 + p u),  u >= 0.
+// GELU and GELU' share the one exponential: with u = |x|/sqrt(2), e^{-u^2} = e^{-x^2/2} is also the
+// normal pdf up to 1/sqrt(2 pi).
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+  const float u = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+  const float e = __expf(-u * u);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erf_abs = fmaf(-poly * t, e, 1.0f);
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+  pdf = 0.39894228040143268f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return x * cdf;
+}
 __device__ __forceinline__ float dgelu_f(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  return fmaf(x, pdf, cdf);
 }
 
 // counter-based RNG for dropout: one 32-bit hash per element index (same mask in fwd and bwd)

@@ -19,7 +19,8 @@ class GemmArgs(C.Structure):
         "res_row_mod", "res_row_off", "out_seg_rows", "out_seg_skip", "out_row_off", "reserved")] + [
         (n, vp) for n in ("A", "B", "C", "bias", "residual", "aux")] + [
         (n, i64) for n in ("lda", "ldb", "ldc", "ldr", "ldaux",
-                           "stride_a", "stride_b", "stride_c", "stride_bias", "stride_r", "stride_aux")]
+                           "stride_a", "stride_b", "stride_c", "stride_bias", "stride_r", "stride_aux")] + [
+        ("workspace", vp), ("workspace_bytes", i64), ("colsum", vp)]
 
 
 # name -> argtypes; every function returns int except the two noted below
@@ -28,7 +29,7 @@ SIGNATURES = {
     "xvit_small_linear_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "xvit_small_linear_bwd": [vp, vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp],
     "xvit_layernorm_fwd": [vp, vp, i64, i32, vp, vp, f32, vp, i64, vp, vp, i32, i32, vp],
-    "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, vp],
+    "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp],
     "xvit_attn_fwd": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, vp],
     "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "xvit_cls_xattn_fwd": [vp, i64, vp, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp],
@@ -41,7 +42,7 @@ SIGNATURES = {
     "xvit_dropout": [vp, vp, i32, i64, f32, u64, vp],
     "xvit_mean_ce": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp],
 }
-EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string"])
+EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string", "xvit_gemm_workspace_bytes"])
 
 _lib = None
 
@@ -58,6 +59,8 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)
             fn.argtypes = argtypes
             fn.restype = C.c_int
+        lib.xvit_gemm_workspace_bytes.argtypes = [C.POINTER(GemmArgs)]
+        lib.xvit_gemm_workspace_bytes.restype = C.c_int64
         lib.xvit_version.restype = C.c_int
         lib.xvit_last_error_string.restype = C.c_char_p
         _lib = lib

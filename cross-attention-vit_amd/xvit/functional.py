@@ -82,29 +82,39 @@ def invalidate_shadows():
 
 def _wgrad_split(m, n, k):
     """Split-K factor for a TN wgrad: enough workgroups to fill 256 CUs, >= 8 K-steps each."""
+    if m >= 256 and n >= 256:   # 256x256 tiles, one block per CU
+        tiles = ((m + 255) // 256) * ((n + 255) // 256)
+        return max(1, min(256 // max(tiles, 1), ((k + 63) // 64) // 8, 16))
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
-    ksteps = (k + 63) // 64
-    s = max(1, min(512 // max(tiles, 1), ksteps // 8, 32))
-    return s
+    return max(1, min(512 // max(tiles, 1), ((k + 63) // 64) // 8, 32))
 
 
 def _wgrad(dy_b, x_b):
     """dW[out, in] = dy^T x over all rows (tokens); fp32."""
     out_f, in_f, k = dy_b.shape[1], x_b.shape[1], dy_b.shape[0]
-    s = _wgrad_split(out_f, in_f, k)
-    dW = (torch.zeros if s > 1 else torch.empty)(out_f, in_f, dtype=torch.float32, device=dy_b.device)
-    ops.gemm(ops.TN, dy_b, x_b, dW, split_k=s)
+    dW = torch.empty(out_f, in_f, dtype=torch.float32, device=dy_b.device)
+    ops.gemm(ops.TN, dy_b, x_b, dW, split_k=_wgrad_split(out_f, in_f, k))
     return dW
+
+
+def _skinny_split(m, n, k):
+    """Few-row GEMMs (the 1-token cross-attention path, heads) are bound by the latency of their serial
+    K loop, not by FLOPs: cut K so ~100 workgroups stream the weight matrix concurrently."""
+    if m > 128:
+        return 1
+    tiles = (n + 127) // 128
+    return max(1, min(((k + 63) // 64) // 4, 96 // tiles))
 
 
 def _linear(x_b, w_s, *, bias=None, residual=None, act=ops.ACT_NONE, aux=None, out_dtype=torch.bfloat16, **kw):
     y = torch.empty(x_b.shape[0], w_s.shape[0], dtype=out_dtype, device=x_b.device)
-    return ops.gemm(ops.NT, x_b, w_s, y, bias=bias, residual=residual, act=act, aux=aux, **kw)
+    return ops.gemm(ops.NT, x_b, w_s, y, bias=bias, residual=residual, act=act, aux=aux,
+                    split_k=_skinny_split(x_b.shape[0], w_s.shape[0], w_s.shape[1]), **kw)
 
 
-def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None):
+def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None, colsum=None):
     dx = torch.empty(dy_b.shape[0], w_s.shape[1], dtype=torch.bfloat16, device=dy_b.device)
-    return ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux)
+    return ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=colsum, split_k=_skinny_split(dy_b.shape[0], w_s.shape[1], w_s.shape[0]))
 
 
 def _zeros(n, ref):
@@ -136,30 +146,28 @@ def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln
 
 
 def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w, w1_s, w2_s, need_dx=True):
-    """dy fp32 [B*N, d] -> (dx, grads dict)."""
+    """dy fp32 [B*N, d] -> (dx, grads dict).  Bias gradients cost no extra pass: b2 and bo fall out of the
+    LN2 backward (column sums of its dres and dx), b1 out of the GELU' dgrad epilogue."""
     x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a = saved
-    d = x.shape[1]
-    g = {}
+    d, f = x.shape[1], z.shape[1]
+    zero = torch.zeros(6 * d + f, dtype=torch.float32, device=x.device)   # every atomically-accumulated vector of this block
+    g = dict(zip(("ln2w", "ln2b", "bo", "b2", "ln1w", "ln1b"), zero[:6 * d].split(d)))
+    g["b1"] = zero[6 * d:]
     dyb = ops.cast_bf16(dy)
     # FFN
-    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z)
+    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"])
     g["w2"] = _wgrad(dyb, a)
-    g["b2"] = ops.colsum(dy)
     dh2 = _dgrad(dz, w1_s)
     g["w1"] = _wgrad(dz, h2)
-    g["b1"] = ops.colsum(dz)
-    g["ln2w"], g["ln2b"] = _zeros(d, x), _zeros(d, x)
-    dx1, dx1b = ops.layernorm_bwd(dh2, x1, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy, want_bf16=True)
+    dx1, dx1b = ops.layernorm_bwd(dh2, x1, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy, want_bf16=True, dxsum=g["bo"], dressum=g["b2"])
     # attention
     do = _dgrad(dx1b, wo_s)
     g["wo"] = _wgrad(dx1b, o)
-    g["bo"] = ops.colsum(dx1)
     dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale)
     dh1 = _dgrad(dqkv, wqkv_s)
     g["wqkv"] = _wgrad(dqkv, h1)
     if has_bqkv:
         g["bqkv"] = ops.colsum(dqkv)
-    g["ln1w"], g["ln1b"] = _zeros(d, x), _zeros(d, x)
     dx, _ = ops.layernorm_bwd(dh1, x, mu1, rs1, ln1w, g["ln1w"], g["ln1b"], dres=dx1)
     return dx, g
 
@@ -235,21 +243,19 @@ def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq_s, bq, wkv_s, bkv, wp_s, 
 def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s):
     """dy2 fp32 [B, d] -> (dcat fp32 [B*N, d] = grad of the normed concat input, dcls_res fp32 [B, d], grads)."""
     xi, xj, mu, rs, hn, kv, q, oc, p, y, mu2, rs2, h2, z, a = saved
-    d = xi.shape[1]
+    d, f = xi.shape[1], z.shape[1]
     scale = (d // H) ** -0.5
-    g = {}
+    zero = torch.zeros(6 * d + f, dtype=torch.float32, device=xi.device)
+    g = dict(zip(("ln2w", "ln2b", "bp", "b2", "ln1w", "ln1b"), zero[:6 * d].split(d)))
+    g["b1"] = zero[6 * d:]
     dyb = ops.cast_bf16(dy2)
-    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z)
+    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"])
     g["w2"] = _wgrad(dyb, a)
-    g["b2"] = ops.colsum(dy2)
     dh2 = _dgrad(dz, w1_s)
     g["w1"] = _wgrad(dz, h2)
-    g["b1"] = ops.colsum(dz)
-    g["ln2w"], g["ln2b"] = _zeros(d, xi), _zeros(d, xi)
-    dy, dyb1 = ops.layernorm_bwd(dh2, y, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy2, want_bf16=True)
+    dy, dyb1 = ops.layernorm_bwd(dh2, y, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy2, want_bf16=True, dxsum=g["bp"], dressum=g["b2"])
     doc = _dgrad(dyb1, wp_s)
     g["wp"] = _wgrad(dyb1, oc)
-    g["bp"] = ops.colsum(dy)
     dq, dkv = ops.cls_xattn_bwd(q, kv, p, doc, B, N, H, scale)
     dqb = ops.cast_bf16(dq)
     dhn = _dgrad(dkv, wkv_s)                                # [B*N, d] bf16
@@ -261,7 +267,6 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
     g["bkv"] = ops.colsum(dkv)
     g["wq"] = _wgrad(dqb, hn0)
     g["bq"] = ops.colsum(dq)
-    g["ln1w"], g["ln1b"] = _zeros(d, xi), _zeros(d, xi)
     dcat, _ = ops.layernorm_bwd(dhn, xj, mu, rs, ln1w, g["ln1w"], g["ln1b"], x_alt=xi, seq_len=N)
     return dcat, dy, g
 

@@ -23,6 +23,7 @@ def _stream() -> int:
 # launch with HIP events recorded on the launch stream and appends
 # (kernel family, algorithmic work, "flop" | "byte", start_event, end_event).
 PROFILE = None
+PROFILE_SHAPES = False   # append the GEMM shape/epilogue to the family name (bench.py --detail)
 
 
 def _run(name, work, kind, rc_fn, what):
@@ -59,7 +60,7 @@ def _rows2d(t):
 
 
 def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NONE, accumulate=False,
-         split_k=1, res_row_mod=0, res_row_off=0, out_seg=(0, 0, 0), M=None, N=None, K=None):
+         split_k=1, res_row_mod=0, res_row_off=0, out_seg=(0, 0, 0), M=None, N=None, K=None, colsum=None):
     """C = op(A) op(B) with the fused epilogue of include/xvit.h.  2-D tensors, or 3-D
     [batch, rows, cols] for a strided batch (all of A, B, C and optional bias 2-D / residual /
     aux 3-D then carry the batch in dim 0)."""
@@ -99,7 +100,20 @@ def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NON
         a.aux, a.ldaux = _ptr(aux), _rows2d(x2)
         if batched:
             a.stride_aux = aux.stride(0)
-    _run(("gemm_nt", "gemm_nn", "gemm_tn")[layout], 2.0 * a.M * a.N * a.K * a.batch, "flop",
+    if colsum is not None:
+        assert colsum.dtype == torch.float32
+        a.colsum = _ptr(colsum)
+    ws = None
+    if split_k > 1:
+        need = _lib.load().xvit_gemm_workspace_bytes(C.byref(a))
+        if need:
+            ws = torch.empty(need // 4, dtype=torch.float32, device=C_out.device)
+            a.workspace, a.workspace_bytes = _ptr(ws), need
+    tag = ("gemm_nt", "gemm_nn", "gemm_tn")[layout]
+    if PROFILE is not None and PROFILE_SHAPES:
+        epi = ("+b" if bias is not None else "") + ("+gelu" if act == ACT_GELU else "+dgelu" if act == ACT_DGELU else "") + ("+res" if residual is not None else "")
+        tag += f"[{a.M}x{a.N}x{a.K}{epi}{'' if a.c_dtype == BF16 else ',f32'}{',s%d' % split_k if split_k > 1 else ''}]"
+    _run(tag, 2.0 * a.M * a.N * a.K * a.batch, "flop",
          lambda: _lib.load().xvit_gemm(C.byref(a), _stream()), "xvit_gemm")
     return C_out
 
@@ -118,8 +132,9 @@ def layernorm_fwd(x, gamma, beta, eps, *, x_alt=None, seq_len=0, out=None):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, x_alt=None, seq_len=0, dres=None, want_bf16=False):
-    """-> (dx fp32, dx_bf16 | None); dgamma/dbeta (fp32, [d]) are accumulated into."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, x_alt=None, seq_len=0, dres=None, want_bf16=False, dxsum=None, dressum=None):
+    """-> (dx fp32, dx_bf16 | None); dgamma/dbeta (fp32, [d]) are accumulated into; so are the optional
+    column sums dxsum (of dx) and dressum (of dres)."""
     rows, d = x.shape
     dx = torch.empty(rows, d, dtype=torch.float32, device=x.device)
     dxb = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
@@ -127,7 +142,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, x_alt=None, seq_le
     _run("layernorm_bwd", nbytes, "byte", lambda: _lib.load().xvit_layernorm_bwd(
         _ptr(dy), _rows2d(dy), _ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(mean), _ptr(rstd), _ptr(gamma),
         _ptr(dres), _rows2d(dres) if dres is not None else 0, _ptr(dx), d, _ptr(dxb), d,
-        _ptr(dgamma), _ptr(dbeta), rows, d, _stream()), "xvit_layernorm_bwd")
+        _ptr(dgamma), _ptr(dbeta), _ptr(dxsum), _ptr(dressum), rows, d, _stream()), "xvit_layernorm_bwd")
     return dx, dxb
 
 

@@ -57,7 +57,9 @@ typedef struct xvit_gemm_args {
   int32_t c_dtype;    /* XVIT_BF16 | XVIT_F32 */
   int32_t act;        /* XVIT_ACT_* */
   int32_t accumulate; /* XVIT_ACC_* */
-  int32_t split_k;    /* >=1.  >1: fp32 C, partial sums added atomically (C must hold the value to add to) */
+  int32_t split_k;    /* >=1.  >1: the contraction is cut into split_k ranges whose fp32 partial tiles go to the
+                         workspace (xvit_gemm_workspace_bytes(args) bytes); a second kernel sums them in a fixed
+                         order and applies the epilogue (deterministic, no atomics) */
   /* residual row = res_row_off + (row % res_row_mod) when res_row_mod > 0 (broadcast, e.g. pos_embedding) */
   int32_t res_row_mod, res_row_off;
   /* output row = row + (row / out_seg_rows) * out_seg_skip + out_row_off when out_seg_rows > 0
@@ -70,9 +72,15 @@ typedef struct xvit_gemm_args {
   void* aux;             /* bf16 [M, N] or NULL (see act) */
   int64_t lda, ldb, ldc, ldr, ldaux;                                  /* leading dims, elements */
   int64_t stride_a, stride_b, stride_c, stride_bias, stride_r, stride_aux; /* per-batch strides */
+  void* workspace;         /* caller-owned scratch for split_k > 1 (fp32 partial tiles), else NULL */
+  int64_t workspace_bytes;
+  float* colsum;           /* optional fp32 [N]: colsum[n] += sum over rows of the stored C (bias gradient of the
+                              producing Linear, e.g. dz of FeedForward); per-batch stride = stride_bias */
 } xvit_gemm_args;
 
 int xvit_gemm(const xvit_gemm_args* args, xvit_stream_t stream);
+/* scratch needed by xvit_gemm for these args (0 when none); no launch, no allocation */
+int64_t xvit_gemm_workspace_bytes(const xvit_gemm_args* args);
 
 /* Tiny fp32 linear for shapes the MFMA tile cannot address (the num_classes=2 head,
  * model_cross.py:181).  y[M,N] = x[M,K] W[N,K]^T + b.  x is bf16, W/b/y fp32.  */
@@ -91,11 +99,13 @@ int xvit_small_linear_bwd(const float* dy, const void* x_bf16, int64_t ldx, cons
 int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_len, const float* gamma, const float* beta,
                        float eps, void* y_bf16, int64_t ldy, float* mean, float* rstd, int rows, int d, xvit_stream_t stream);
 /* dx = (dres ? dres : 0) + LN'(dy); also emits a bf16 copy of dx (the next GEMMs' operand) when
- * dx_bf16 != NULL; dgamma/dbeta are ADDED (fp32 atomics). */
+ * dx_bf16 != NULL; dgamma/dbeta are ADDED (fp32 atomics).  Optional dxsum[d] += column sums of dx and
+ * dressum[d] += column sums of dres: the bias gradients of the Linears on either side of the norm
+ * (dx is the dy of the Linear that produced x; dres the dy of the Linear whose output joined x), for free. */
 int xvit_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len,
                        const float* mean, const float* rstd, const float* gamma, const float* dres, int64_t lddres,
-                       float* dx, int64_t lddx, void* dx_bf16, int64_t lddxb, float* dgamma, float* dbeta, int rows, int d,
-                       xvit_stream_t stream);
+                       float* dx, int64_t lddx, void* dx_bf16, int64_t lddxb, float* dgamma, float* dbeta, float* dxsum,
+                       float* dressum, int rows, int d, xvit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused self-attention (model_cross.py:53-60; model.py:165-172): softmax(q k^T * scale) v

@@ -22,7 +22,8 @@ def _dgelu(x):
     return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
 
 
-SHAPES = [(64, 128, 64), (200, 192, 128), (1026, 768, 768), (130, 576, 192), (513, 2304, 768), (33, 3072, 768), (2, 768, 768)]
+SHAPES = [(64, 128, 64), (200, 192, 128), (1026, 768, 768), (130, 576, 192), (513, 2304, 768), (33, 3072, 768), (2, 768, 768),
+          (256, 256, 64), (1300, 1000, 320), (2052, 768, 3072)]  # the last rows run on the 256x256 big-tile kernel
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -46,17 +47,17 @@ def test_nn_dgrad(M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,split", [(192, 128, 200, 1), (768, 768, 1026, 1), (768, 3072, 1026, 3), (2304, 768, 513, 2),
-                                         (576, 192, 34, 1), (768, 768, 4104, 8), (128, 4096, 1024, 2)])
+                                         (576, 192, 34, 1), (768, 768, 4104, 8), (128, 4096, 1024, 2), (304, 264, 130, 3), (768, 768, 330, 4)])
 def test_tn_wgrad(M, N, K, split):
     """dW[M,N] = dy[K,M]^T @ x[K,N]: the contraction (tokens) is the row index of both operands and
     need not be a multiple of anything (zero-filled by the DMA)."""
     ops = _ops()
     dy, x = rt(randn(K, M, seed=5)), rt(randn(K, N, seed=6))
-    C = torch.zeros(M, N, dtype=torch.float32, device=dev())
+    C = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev())   # split-K must not depend on C's contents
     ops.gemm(ops.TN, dy.to(dev(), torch.bfloat16), x.to(dev(), torch.bfloat16), C, split_k=split)
     assert_close(C, dy.T @ x, f"TN {M}x{N}x{K} split{split}")
     # accumulate on top (beta = 1)
-    ops.gemm(ops.TN, dy.to(dev(), torch.bfloat16), x.to(dev(), torch.bfloat16), C, split_k=split, accumulate=(split == 1))
+    ops.gemm(ops.TN, dy.to(dev(), torch.bfloat16), x.to(dev(), torch.bfloat16), C, split_k=split, accumulate=True)
     assert_close(C, 2 * (dy.T @ x), f"TN accumulate {M}x{N}x{K} split{split}")
 
 
@@ -79,6 +80,34 @@ def test_epilogue_dgelu():
     C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
     ops.gemm(ops.NN, dy.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, act=ops.ACT_DGELU, aux=z.to(dev(), torch.bfloat16))
     assert_close(C, (dy @ w) * _dgelu(z), "dgelu")
+
+
+@pytest.mark.parametrize("M,split", [(1026, 1), (32, 1), (32, 6), (300, 3)])
+def test_epilogue_dgelu_colsum_and_split(M, split):
+    """GELU' epilogue + column sums of the result (bias gradient), direct and through the split-K
+    second pass (small-M GEMMs are split to hide their serial K loop)."""
+    ops = _ops()
+    N, K = 3072, 768
+    dy, w, z = rt(randn(M, K, seed=1)), rt(randn(K, N, seed=2, scale=K ** -0.5)), rt(randn(M, N, seed=3))
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    cs = torch.zeros(N, device=dev())
+    ops.gemm(ops.NN, dy.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, act=ops.ACT_DGELU, aux=z.to(dev(), torch.bfloat16), colsum=cs, split_k=split)
+    ref = (dy @ w) * _dgelu(z)
+    assert_close(C, ref, "dgelu")
+    assert_close(cs, ref.sum(0), "colsum of the epilogue output")
+
+
+@pytest.mark.parametrize("M,N,K,split", [(32, 768, 3072, 8), (32, 3072, 768, 3), (130, 192, 1024, 4)])
+def test_split_k_with_full_epilogue(M, N, K, split):
+    ops = _ops()
+    a, w, b, r = rt(randn(M, K, seed=1)), rt(randn(N, K, seed=2, scale=K ** -0.5)), randn(N, seed=3), randn(M, N, seed=4)
+    C = torch.empty(M, N, dtype=torch.float32, device=dev())
+    ops.gemm(ops.NT, a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, bias=b.to(dev()), residual=r.to(dev()), split_k=split)
+    assert_close(C, a @ w.T + b + r, "split-K bias+residual")
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    Z = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    ops.gemm(ops.NT, a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), Cb, bias=b.to(dev()), act=ops.ACT_GELU, aux=Z, split_k=split)
+    assert_close(Z, a @ w.T + b, "split-K pre-activation"); assert_close(Cb, _gelu(a @ w.T + b), "split-K gelu")
 
 
 def test_epilogue_bias_residual_f32():

@@ -30,8 +30,12 @@ def test_layernorm_fwd_bwd(rows, d):
     xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
     R.layer_norm(xr, gr, br, 1e-5).backward(dy)
     dg = torch.zeros(d, device=dev()); db = torch.zeros(d, device=dev())
-    dx, dxb = ops.layernorm_bwd(dy.to(dev(), torch.bfloat16), x.to(dev()), mean, rstd, g.to(dev()), dg, db, dres=dres.to(dev()), want_bf16=True)
+    sx = torch.zeros(d, device=dev()); sr = torch.zeros(d, device=dev())
+    dx, dxb = ops.layernorm_bwd(dy.to(dev(), torch.bfloat16), x.to(dev()), mean, rstd, g.to(dev()), dg, db, dres=dres.to(dev()), want_bf16=True,
+                                dxsum=sx, dressum=sr)
     assert_close(dx, xr.grad + dres, "ln dx (+residual)")
+    assert_close(sx, (xr.grad + dres).sum(0), "column sums of dx")
+    assert_close(sr, dres.sum(0), "column sums of dres")
     assert_close(dxb, xr.grad + dres, "ln dx bf16 copy")
     assert_close(dg, gr.grad, "dgamma")
     assert_close(db, br.grad, "dbeta")
