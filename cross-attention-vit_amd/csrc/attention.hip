@@ -20,6 +20,7 @@ constexpr int DH = 64;          // head dim
 constexpr int TILE_ROWS = 64;   // streamed rows per iteration
 constexpr int IMG_BYTES = TILE_ROWS * DH * 2;  // 8 KiB
 constexpr float LOG2E = 1.4426950408889634f;
+constexpr int FWD_NST = 3;     // K/V ring depth of the forward kernel (prefetch distance 2 tiles)
 
 // chunk swizzle for a [rows][128 B] image: conflict-free for b128 row reads and tr reads
 __device__ __forceinline__ int swz_img(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
@@ -97,6 +98,19 @@ __device__ __forceinline__ void load_lane_operand(bf16x8 (&f)[4], const bf16* ba
   }
 }
 
+// Make hipcc's vmcnt scoreboard see these (ordinary) loads as COMPLETE here: the empty asm consumes the
+// registers, so the compiler waits for them now — otherwise it re-waits at their first use inside the tile
+// loop with a conservative vmcnt(0..3), which would also drain the LDS-DMA ring every iteration.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ void settle(bf16x8 (&f)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u32x4 t = __builtin_bit_cast(u32x4, f[i]);
+    asm volatile("" : "+v"(t));
+    f[i] = __builtin_bit_cast(bf16x8, t);
+  }
+}
+
 // element index inside a 32-row accumulator block held in register i by lane half h
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
@@ -130,84 +144,121 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
   const int64_t off = (int64_t)b * sb + head * DH;
   const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
 
+  // K/V tiles stream through a FWD_NST-deep LDS ring.  Loads stay in flight ACROSS iterations: each wave
+  // issues exactly 4 LDS-DMA instructions per tile (2 K + 2 V), so "tile t has landed, tile t+1 may still be
+  // in flight" is a counted s_waitcnt vmcnt(4); barriers are raw s_barrier (a __syncthreads() would drain
+  // vmcnt to 0 and serialise every iteration behind a full HBM/L2 round trip).
   TileLoader lk, lv;
   lk.init(k + off, sn, N, wave, lane);
   lv.init(v + off, sn, N, wave, lane);
-  lk.issue(smem, wave, 0);
-  lv.issue(smem + IMG_BYTES, wave, 0);
-
+#pragma unroll
+  for (int st = 0; st < FWD_NST - 1; ++st)
+    if (st < ntiles) {
+      lk.issue(smem + st * 2 * IMG_BYTES, wave, st);
+      lv.issue(smem + st * 2 * IMG_BYTES + IMG_BYTES, wave, st);
+    }
   bf16x8 qf[4];
-  load_lane_operand(qf, q + off, sn, q0, N, lane);
+  load_lane_operand(qf, q + off, sn, q0, N, lane);   // one round trip together with the first ring tiles
+  settle(qf);                                        // (drains the prologue's DMAs too: fine, they are needed first)
   ImgReader rd;
   rd.init(lane);
 
   const int h = lane >> 5;
   const float c = scale * LOG2E;
+  const bool wave_active = q0 < N;   // wave-uniform
   float m_run = -INFINITY, l_run = 0.f;
   f32x16 oacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
 
+  int stage = 0;
   for (int t = 0; t < ntiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < ntiles) {
-      XVIT_LDS char* nxt = smem + ((t + 1) & 1) * 2 * IMG_BYTES;
-      lk.issue(nxt, wave, t + 1);
-      lv.issue(nxt + IMG_BYTES, wave, t + 1);
+    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t landed; t+1 may be in flight
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of tile t are in LDS; every wave is done with tile t-1
+    if (t + FWD_NST - 1 < ntiles) {
+      int ns = stage + FWD_NST - 1;
+      if (ns >= FWD_NST) ns -= FWD_NST;
+      lk.issue(smem + ns * 2 * IMG_BYTES, wave, t + FWD_NST - 1);
+      lv.issue(smem + ns * 2 * IMG_BYTES + IMG_BYTES, wave, t + FWD_NST - 1);
     }
-    const XVIT_LDS char* kimg = smem + (t & 1) * 2 * IMG_BYTES;
+    const XVIT_LDS char* kimg = smem + stage * 2 * IMG_BYTES;
     const XVIT_LDS char* vimg = kimg + IMG_BYTES;
+    stage = stage + 1 == FWD_NST ? 0 : stage + 1;
+
+    if (!wave_active) continue;   // this wave's 32 queries are all past N: keep moving tiles and barriers, skip the math
+    // keys of this tile past N: with <= 32 valid keys the second 32-key block is skipped entirely
+    const int valid = N - t * TILE_ROWS;
+    const bool two = valid > 32;
 
     // S^T[key][query] = K Q^T
     f32x16 s[2];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = -INFINITY; }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+    for (int ks = 0; ks < 4; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, 0, ks), qf[ks], s[0], 0, 0, 0);
+    if (two) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, kb, ks), qf[ks], s[kb], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) s[1][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, 1, ks), qf[ks], s[1], 0, 0, 0);
     }
-    if (t == ntiles - 1 && (N & (TILE_ROWS - 1))) {  // mask the keys past N
-      const int kbase = t * TILE_ROWS;
+    if (valid < TILE_ROWS) {  // mask the keys past N
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          if (kbase + kb * 32 + acc_row(i, h) >= N) s[kb][i] = -INFINITY;
+          if (kb * 32 + acc_row(i, h) >= valid) s[kb][i] = -INFINITY;
     }
     // online softmax; the query is this lane's column, split over the two lane halves
     float mx = s[0][0];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
+    if (two) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    m_run = m_new;
+    if (__any(mx > m_run)) {   // some row's running max moved: rescale (otherwise alpha == 1 exactly, skip the pass)
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+    }
+    const float mc = m_run * c;
     float psum = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int i = 0; i < 16; ++i) {
+      const float pv = __builtin_amdgcn_exp2f(fmaf(s[0][i], c, -mc));
+      s[0][i] = pv;
+      psum += pv;
+    }
+    if (two) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][i], c, -mc));
-        s[kb][i] = pv;
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[1][i], c, -mc));
+        s[1][i] = pv;
         psum += pv;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
+    }
+    l_run += psum;
     // O^T[d][query] += V^T P^T
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+    for (int ss = 0; ss < 2; ++ss) {
+      const bf16x8 pf = acc_frag(s[0], ss);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(vimg, db, 0, ss), pf, oacc[db], 0, 0, 0);
+    }
+    if (two) {
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 pf = acc_frag(s[kb], ss);
+        const bf16x8 pf = acc_frag(s[1], ss);
 #pragma unroll
-        for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(vimg, db, kb, ss), pf, oacc[db], 0, 0, 0);
+        for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(vimg, db, 1, ss), pf, oacc[db], 0, 0, 0);
       }
+    }
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const int qrow = q0 + (lane & 31);
@@ -267,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 
   const int qrow = q0 + (lane & 31);
   const bool valid = qrow < N;
+  const bool wave_active = q0 < N;   // wave-uniform
   const int64_t stat = ((int64_t)b * H + head) * N + qrow;
   const float c = scale * LOG2E;
   // invalid query rows: lse = +big -> P = 0, so nothing is accumulated for them
@@ -287,8 +339,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
     }
     const XVIT_LDS char* kimg = smem + (t & 1) * 2 * IMG_BYTES;
     const XVIT_LDS char* vimg = kimg + IMG_BYTES;
+    if (!wave_active) continue;
+    const int nkb = (N - t * TILE_ROWS) > 32 ? 2 : 1;   // a tail tile with <= 32 keys needs one key block only
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (kb >= nkb) break;
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -357,6 +412,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   rd.init(lane);
   const int h = lane >> 5;
   const float c = scale * LOG2E;
+  const bool wave_active = k0 < N;   // wave-uniform
 
   f32x16 dkacc[2], dvacc[2];
 #pragma unroll
@@ -375,8 +431,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
     const XVIT_LDS char* doimg = qimg + IMG_BYTES;
     const XVIT_LDS float* st_lse = (const XVIT_LDS float*)(qimg + 2 * IMG_BYTES);
     const XVIT_LDS float* st_dlt = st_lse + 64;
+    if (!wave_active) continue;
+    const int nqb = (N - t * TILE_ROWS) > 32 ? 2 : 1;   // a tail tile with <= 32 queries needs one query block only
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
+      if (qb >= nqb) break;
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -431,7 +490,7 @@ extern "C" int xvit_attn_fwd(const void* q, const void* k, const void* v, int64_
   XVIT_REQUIRE(q && k && v && o && lse, "xvit_attn_fwd: null pointer");
   if (int e = attn_check("xvit_attn_fwd", B, H, N, dh, sb, sn, osb, osn)) return e;
   const dim3 grid((N + 127) / 128, H, B), block(256);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 4 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, FWD_NST * 2 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
                      (bf16*)o, osb, osn, lse, H, N, scale);
   return check_launch("xvit_attn_fwd");
 }

@@ -11,6 +11,8 @@ parameter containers with the reference's names — their torch forward is never
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -160,8 +162,35 @@ class MultiScaleBlock(nn.Module):
         self.blocks = nn.ModuleList(branch() for _ in range(config.num_modalities))   # separate weights per modality
         self.fusion = nn.ModuleList(CrossAttentionBlock(config) for _ in self.attn_order)
 
+    _streams: dict = {}
+
+    @classmethod
+    def _branch_streams(cls, device, n):
+        key = (device, n)
+        if key not in cls._streams:
+            cls._streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+        return cls._streams[key]
+
+    def _branches(self, x):
+        """The M modality branches are independent until fusion (separate weights, :122): run each on
+        its own HIP stream so their kernels interleave on the chip (one GEMM's tail round / HBM-bound
+        epilogue overlaps the other's MFMA phase).  autograd replays backward on the same streams."""
+        if len(x) < 2 or not x[0].is_cuda or os.environ.get("XVIT_STREAMS", "1") == "0":
+            return [block(x_) for x_, block in zip(x, self.blocks)]
+        cur = torch.cuda.current_stream(x[0].device)
+        outs = []
+        for x_, block, st in zip(x, self.blocks, self._branch_streams(x[0].device, len(x))):
+            st.wait_stream(cur)
+            x_.record_stream(st)
+            with torch.cuda.stream(st):
+                outs.append(block(x_))
+        for y, st in zip(outs, self._branch_streams(x[0].device, len(x))):
+            cur.wait_stream(st)
+            y.record_stream(cur)
+        return outs
+
     def forward(self, x):
-        attn = [block(x_) for x_, block in zip(x, self.blocks)]
+        attn = self._branches(x)
         outs = []
         cross_count = 0
         for i in range(len(self.blocks)):
