@@ -125,8 +125,10 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("XVIT_FORCE_DIST") == "1"   # the latter: rehearse the N>1 code path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import xvit
@@ -140,7 +142,7 @@ def main():
     model = xvit.ModelCross(cfg).to(dev)
     model.train()
     params = [p for p in model.parameters()]
-    reducer = BucketedGradReducer(params, bucket_bytes=32 << 20) if world > 1 else None
+    reducer = BucketedGradReducer(params, bucket_bytes=32 << 20) if use_dist else None
 
     gen = torch.Generator().manual_seed(1234 + rank)
     img = torch.randn(B, M, 1, *cfg.img_size, generator=gen).to(dev, torch.bfloat16)   # random (not zero) data: MI355X_MICROARCH.md DVFS note
@@ -158,7 +160,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -175,7 +177,7 @@ def main():
         loss = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -243,7 +245,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -34,7 +34,8 @@ __device__ __forceinline__ float row_dot8(const float (&a)[8], const bf16* mat, 
 
 __global__ __launch_bounds__(XA_THREADS) void cls_xattn_fwd_kernel(const bf16* __restrict__ q, int64_t ldq, const bf16* __restrict__ k,
                                                                    const bf16* __restrict__ v, int64_t sb, int64_t sn, bf16* __restrict__ o,
-                                                                   int64_t ldo, float* __restrict__ p, int H, int N, float scale) {
+                                                                   int64_t ldo, float* __restrict__ p, int H, int N, float scale, float drop_p,
+                                                                   uint64_t drop_seed) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* sc = (float*)smem_raw;            // [N] scores -> probabilities
   float* red = sc + ((N + 3) & ~3);        // [4] + [32][64] partial outputs
@@ -66,10 +67,14 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_fwd_kernel(const bf16* _
   sum = block_reduce(sum, false, red);
   const float inv = 1.0f / sum;
   float* prow = p + ((int64_t)b * H + head) * N;
+  const uint32_t thr = (uint32_t)(drop_p * 16777216.0f);
+  const float dinv = 1.0f / (1.0f - drop_p);
+  const uint64_t pidx = ((uint64_t)b * H + head) * N;
   for (int n = tid; n < N; n += XA_THREADS) {
     const float pr = sc[n] * inv;
-    sc[n] = pr;
-    prow[n] = pr;
+    prow[n] = pr;                                   // saved pre-dropout (backward regenerates the mask)
+    const bool keep = drop_p <= 0.f || (hash32(drop_seed, pidx + n) & 0xFFFFFFu) >= thr;
+    sc[n] = keep ? pr * (drop_p > 0.f ? dinv : 1.0f) : 0.f;
   }
   __syncthreads();
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_bwd_kernel(const bf16* _
                                                                    const bf16* __restrict__ v, int64_t sb, int64_t sn,
                                                                    const float* __restrict__ p, const bf16* __restrict__ d_o, int64_t lddo,
                                                                    float* __restrict__ dq, int64_t lddq, bf16* __restrict__ dk,
-                                                                   bf16* __restrict__ dv, int H, int N, float scale) {
+                                                                   bf16* __restrict__ dv, int H, int N, float scale, float drop_p,
+                                                                   uint64_t drop_seed) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* ds = (float*)smem_raw;            // [N] dp -> ds
   float* red = ds + ((N + 3) & ~3);
@@ -111,18 +117,24 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_bwd_kernel(const bf16* _
 #pragma unroll
     for (int e = 0; e < 8; ++e) { qv[e] = bf2f(t[e]); gov[e] = bf2f(g[e]); }
   }
-  // dp[n] = do . v[n];   dsum = sum_n p[n] dp[n]
+  // p' = mask * p / (1-pd);  dp[n] = mask/(1-pd) * (do . v[n]);   dsum = sum_n p[n] dp[n]
+  const uint32_t thr = (uint32_t)(drop_p * 16777216.0f);
+  const float dinv = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+  const uint64_t pidx = ((uint64_t)b * H + head) * N;
   float dsum = 0.f;
   for (int n = slice; n < N; n += 32) {
-    const float dp = row_dot8(gov, v + boff, sn, n, part);
+    const float mk = (drop_p <= 0.f || (hash32(drop_seed, pidx + n) & 0xFFFFFFu) >= thr) ? dinv : 0.f;
+    const float dp = row_dot8(gov, v + boff, sn, n, part) * mk;
     if (part == 0) { ds[n] = dp; dsum += prow[n] * dp; }
   }
   dsum = block_reduce(dsum, false, red);
   // ds[n] = p (dp - dsum);  dq += scale * ds[n] k[n];  dk[n] = scale * ds[n] q;  dv[n] = p[n] do
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int n = slice; n < N; n += 32) {
-    const float pr = prow[n];
-    const float dsn = pr * (ds[n] - dsum) * scale;
+    const float mk = (drop_p <= 0.f || (hash32(drop_seed, pidx + n) & 0xFFFFFFu) >= thr) ? dinv : 0.f;
+    const float pr0 = prow[n];
+    const float pr = pr0 * mk;                       // dropped probability feeds dv
+    const float dsn = pr0 * (ds[n] - dsum) * scale;
     const bf16x8 kk = *(const bf16x8*)(k + boff + (int64_t)n * sn + part * 8);
     bf16x8 okk, ovv;
 #pragma unroll
@@ -152,7 +164,8 @@ using namespace xvit;
 static size_t xa_lds(int N) { return (size_t)(((N + 3) & ~3) + 4 + 32 * 64) * sizeof(float); }
 
 extern "C" int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t sb, int64_t sn, void* o, int64_t ldo, float* p,
-                                  int B, int H, int N, int dh, float scale, xvit_stream_t stream) {
+                                  int B, int H, int N, int dh, float scale, float drop_p, uint64_t drop_seed, xvit_stream_t stream) {
+  XVIT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "xvit_cls_xattn_fwd: dropout_p must be in [0, 1)");
   XVIT_REQUIRE(q && k && v && o && p, "xvit_cls_xattn_fwd: null pointer");
   XVIT_REQUIRE(dh == XA_DH, "xvit_cls_xattn_fwd: head dim %d unsupported (only 64)", dh);
   XVIT_REQUIRE(B > 0 && H > 0 && N > 0 && B <= 65535, "xvit_cls_xattn_fwd: bad B/H/N");
@@ -165,13 +178,14 @@ extern "C" int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const void* k, con
     attr = lds;
   }
   hipLaunchKernelGGL(cls_xattn_fwd_kernel, dim3(H, B), dim3(XA_THREADS), lds, (hipStream_t)stream, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, sb,
-                     sn, (bf16*)o, ldo, p, H, N, scale);
+                     sn, (bf16*)o, ldo, p, H, N, scale, drop_p, drop_seed);
   return check_launch("xvit_cls_xattn_fwd");
 }
 
 extern "C" int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t sb, int64_t sn, const float* p, const void* d_o,
                                   int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, int B, int H, int N, int dh, float scale,
-                                  xvit_stream_t stream) {
+                                  float drop_p, uint64_t drop_seed, xvit_stream_t stream) {
+  XVIT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "xvit_cls_xattn_bwd: dropout_p must be in [0, 1)");
   XVIT_REQUIRE(q && k && v && p && d_o && dq && dk && dv, "xvit_cls_xattn_bwd: null pointer");
   XVIT_REQUIRE(dh == XA_DH, "xvit_cls_xattn_bwd: head dim %d unsupported (only 64)", dh);
   XVIT_REQUIRE(B > 0 && H > 0 && N > 0 && B <= 65535, "xvit_cls_xattn_bwd: bad B/H/N");
@@ -184,6 +198,6 @@ extern "C" int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, con
     attr = lds;
   }
   hipLaunchKernelGGL(cls_xattn_bwd_kernel, dim3(H, B), dim3(XA_THREADS), lds, (hipStream_t)stream, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, sb,
-                     sn, p, (const bf16*)d_o, lddo, dq, lddq, (bf16*)dk, (bf16*)dv, H, N, scale);
+                     sn, p, (const bf16*)d_o, lddo, dq, lddq, (bf16*)dk, (bf16*)dv, H, N, scale, drop_p, drop_seed);
   return check_launch("xvit_cls_xattn_bwd");
 }

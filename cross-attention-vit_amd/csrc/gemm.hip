@@ -22,6 +22,7 @@ struct GemmParams {
   int res_row_mod, res_row_off, seg_rows, seg_skip, row_off;
   float* slab;          // split-K partial sums [split][batch][M][N], else nullptr
   float* colsum;        // optional [N] fp32: += column sums of the stored C
+  float drop_p, drop_inv; uint64_t drop_seed;   // dropout after the activation, before the residual (p == 0: off)
 };
 
 // ---- the fused epilogue, shared by both tile kernels and the split-K reduce kernel -------------
@@ -41,6 +42,12 @@ __device__ __forceinline__ f32x4 epilogue_apply(const GemmParams& p, f32x4 v, in
     const bf16x4 z = *(const bf16x4*)(aux + (int64_t)row * p.ldaux + col);
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(bf2f(z[e]));
+  }
+  if (p.drop_p > 0.f) {   // mask keyed by (seed, batch-local element index): regenerated, never stored
+    const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+    const uint64_t idx = (uint64_t)(cb / (p.sC ? p.sC : 1)) * ((uint64_t)p.M * p.N) + (uint64_t)row * p.N + col;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (hash32(p.drop_seed, idx + e) & 0xFFFFFFu) >= thr ? v[e] * p.drop_inv : 0.f;
   }
   if (res) {
     const int rr = p.res_row_mod > 0 ? p.res_row_off + (row % p.res_row_mod) : row;
@@ -536,6 +543,8 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   p.seg_rows = a->out_seg_rows; p.seg_skip = a->out_seg_skip; p.row_off = a->out_row_off;
   p.slab = ws_need > 0 ? (float*)a->workspace : nullptr;
   p.colsum = a->colsum;
+  XVIT_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "xvit_gemm: dropout_p must be in [0, 1)");
+  p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
   hipStream_t s = (hipStream_t)stream;
 
   static bool attr_done = false;

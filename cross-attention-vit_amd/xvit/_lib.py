@@ -20,7 +20,7 @@ class GemmArgs(C.Structure):
         (n, vp) for n in ("A", "B", "C", "bias", "residual", "aux")] + [
         (n, i64) for n in ("lda", "ldb", "ldc", "ldr", "ldaux",
                            "stride_a", "stride_b", "stride_c", "stride_bias", "stride_r", "stride_aux")] + [
-        ("workspace", vp), ("workspace_bytes", i64), ("colsum", vp)]
+        ("workspace", vp), ("workspace_bytes", i64), ("colsum", vp), ("dropout_p", f32), ("reserved2", i32), ("dropout_seed", u64)]
 
 
 # name -> argtypes; every function returns int except the two noted below
@@ -32,8 +32,8 @@ SIGNATURES = {
     "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp],
     "xvit_attn_fwd": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, vp],
     "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
-    "xvit_cls_xattn_fwd": [vp, i64, vp, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, f32, vp],
-    "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, f32, vp],
+    "xvit_cls_xattn_fwd": [vp, i64, vp, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
+    "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "xvit_cls_row_fwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_embed_bwd": [vp, vp, vp, i32, i32, i32, vp],

@@ -36,11 +36,11 @@ def _mlp_container(config, out_dim):
                          _lin(config.mlp_dim, out_dim), nn.Dropout(config.dropout))
 
 
-def _check_dropout(module, p):
-    if module.training and p > 0.0:
-        raise NotImplementedError(
-            "xvit: dropout > 0 in training mode is not wired into the fused HIP blocks yet "
-            "(parity is defined at dropout = 0 / eval); set config.dropout = 0 or call .eval()")
+def _p(module, drop):
+    """Active dropout probability of an nn.Dropout child: its p in training mode, else 0 (nn.Dropout semantics).
+    Masks come from a counter hash (xvit_dropout), so they cannot bit-match torch's Philox stream: parity is
+    defined at p = 0 / eval; in training the layers are statistically equivalent."""
+    return float(drop.p) if module.training else 0.0
 
 
 class PreNorm(nn.Module):
@@ -63,8 +63,7 @@ class FeedForward(nn.Module):
         self.net = _mlp_container(config, config.hidden_dim)
 
     def forward(self, x):
-        _check_dropout(self, self.net[2].p)
-        return XF.FeedForwardFn.apply(x, self.net[0].weight, self.net[0].bias, self.net[3].weight, self.net[3].bias)
+        return XF.FeedForwardFn.apply(x, self.net[0].weight, self.net[0].bias, self.net[3].weight, self.net[3].bias, _p(self, self.net[2]))
 
 
 class Attention(nn.Module):
@@ -85,8 +84,7 @@ class Attention(nn.Module):
         out = XF.AttentionCoreFn.apply(qkv, self.heads, self.scale)
         if isinstance(self.to_out, nn.Identity):
             return out
-        _check_dropout(self, self.to_out[1].p)
-        return XF.LinearFn.apply(out, self.to_out[0].weight, self.to_out[0].bias, True)
+        return XF.LinearFn.apply(out, self.to_out[0].weight, self.to_out[0].bias, True, _p(self, self.to_out[1]))
 
 
 class SelfAttentionBlock(nn.Module):
@@ -102,11 +100,10 @@ class SelfAttentionBlock(nn.Module):
         if isinstance(a.fn.to_out, nn.Identity):  # single-head degenerate case: unfused composition
             x = a(x) + x
             return f(x) + x
-        _check_dropout(self, f.fn.net[2].p)
         return XF.SelfAttentionBlockFn.apply(
             x, a.norm.weight, a.norm.bias, a.fn.to_qkv.weight, a.fn.to_out[0].weight, a.fn.to_out[0].bias,
             f.norm.weight, f.norm.bias, f.fn.net[0].weight, f.fn.net[0].bias, f.fn.net[3].weight, f.fn.net[3].bias,
-            a.fn.heads, a.norm.eps)
+            a.fn.heads, a.norm.eps, _p(self, f.fn.net[2]))
 
 
 class CrossAttention(nn.Module):
@@ -122,13 +119,12 @@ class CrossAttention(nn.Module):
         self.attn_drop, self.proj_drop = nn.Dropout(config.dropout), nn.Dropout(config.dropout)
 
     def forward(self, x):
-        _check_dropout(self, self.attn_drop.p)
         B, N, C = x.shape
         q = XF.LinearFn.apply(x[:, 0], self.wq.weight, self.wq.bias, False)
         k = XF.LinearFn.apply(x, self.wk.weight, self.wk.bias, False)
         v = XF.LinearFn.apply(x, self.wv.weight, self.wv.bias, False)
-        o = XF.ClsAttentionCoreFn.apply(q, torch.cat((k, v), dim=-1), self.num_heads, self.scale)
-        return XF.LinearFn.apply(o, self.proj.weight, self.proj.bias, True).reshape(B, 1, C)
+        o = XF.ClsAttentionCoreFn.apply(q, torch.cat((k, v), dim=-1), self.num_heads, self.scale, _p(self, self.attn_drop))
+        return XF.LinearFn.apply(o, self.proj.weight, self.proj.bias, True, _p(self, self.proj_drop)).reshape(B, 1, C)
 
 
 def _fusion_args(blk):
@@ -148,8 +144,7 @@ class CrossAttentionBlock(nn.Module):
         self.ffn = PreNorm(config, FeedForward(config))
 
     def forward(self, x):
-        _check_dropout(self, self.attn.fn.attn_drop.p)
-        return XF.CrossFusionFn.apply(x, x, *_fusion_args(self), False)
+        return XF.CrossFusionFn.apply(x, x, *_fusion_args(self), False, _p(self, self.attn.fn.attn_drop))
 
 
 class MultiScaleBlock(nn.Module):
@@ -197,9 +192,8 @@ class MultiScaleBlock(nn.Module):
             if str(i) in self.attn_order:
                 j = int(self.attn_order[str(i)])
                 blk = self.fusion[cross_count]
-                _check_dropout(blk, blk.attn.fn.attn_drop.p)
                 # cls of i + patch tokens of j -> new cls, re-attached to i's own patch tokens (:140-142)
-                outs.append(XF.CrossFusionFn.apply(attn[i], attn[j], *_fusion_args(blk), True))
+                outs.append(XF.CrossFusionFn.apply(attn[i], attn[j], *_fusion_args(blk), True, _p(blk, blk.attn.fn.attn_drop)))
                 cross_count += 1
             else:
                 outs.append(attn[i])
@@ -230,14 +224,13 @@ class ModelCross(_Base):
         self.initialize_model()
 
     def forward(self, img, labels):
-        _check_dropout(self, self.dropout.p)
         if img.shape[1] != self.num_modalities:
             raise ValueError(f"expected {self.num_modalities} modalities, got {img.shape[1]}")
         tokens = XF.PatchEmbedFn.apply(img, self.patch_to_embedding.weight, self.patch_to_embedding.bias,
-                                       self.cls_token, self.pos_embedding, self.patch_size)
+                                       self.cls_token, self.pos_embedding, self.patch_size, _p(self, self.dropout))
         x = self.transformer([tokens[m] for m in range(self.num_modalities)])
         per_mod = [XF.HeadFn.apply(x[m], self.norm[m].weight, self.norm[m].bias, self.mlp_head[m][0].weight, self.mlp_head[m][0].bias,
-                                   self.mlp_head[m][3].weight, self.mlp_head[m][3].bias, self.norm[m].eps)
+                                   self.mlp_head[m][3].weight, self.mlp_head[m][3].bias, self.norm[m].eps, _p(self, self.mlp_head[m][2]))
                    for m in range(self.num_modalities)]
         logits, loss = XF.MeanCrossEntropyFn.apply(torch.stack(per_mod), labels, self.label_smoothing)
         return logits, loss

@@ -11,10 +11,16 @@ import torch.nn as nn
 from . import functional as XF
 
 
-def _no_train_dropout(module, *ps):
-    if module.training and any(p > 0.0 for p in ps):
-        raise NotImplementedError("xvit: dropout > 0 in training mode is not wired into the fused HIP blocks yet; "
-                                  "use dropout_rate = attention_dropout_rate = 0 or .eval()")
+def _p(module, drop):
+    return float(drop.p) if module.training else 0.0
+
+
+def _no_prob_dropout(module, drop):
+    """model.py:169 drops attention PROBABILITIES; the fused attention kernel never materialises them and has
+    no mask hook yet, so training with attention_dropout_rate > 0 is refused rather than silently changed."""
+    if module.training and drop.p > 0.0:
+        raise NotImplementedError("xvit: attention_dropout_rate > 0 in training mode is not supported by the fused "
+                                  "attention kernel (dropout_rate on the MLP is); use 0 or .eval()")
 
 
 class Mlp(nn.Module):
@@ -28,8 +34,7 @@ class Mlp(nn.Module):
         self.dropout = nn.Dropout(t["dropout_rate"])
 
     def forward(self, x):
-        _no_train_dropout(self, self.dropout.p)
-        return XF.FeedForwardFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias)
+        return XF.FeedForwardFn.apply(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, _p(self, self.dropout))
 
 
 class MultiHeadAttention(nn.Module):
@@ -48,12 +53,12 @@ class MultiHeadAttention(nn.Module):
         self.proj_dropout = nn.Dropout(t["attention_dropout_rate"])
 
     def forward(self, x):
-        _no_train_dropout(self, self.attn_dropout.p)
+        _no_prob_dropout(self, self.attn_dropout)
         w = torch.cat((self.query.weight, self.key.weight, self.value.weight), dim=0)
         b = torch.cat((self.query.bias, self.key.bias, self.value.bias), dim=0)
         qkv = XF.LinearFn.apply(x, w, b, False)
         ctxl = XF.AttentionCoreFn.apply(qkv, self.num_attention_heads, 1.0 / float(self.attention_head_size) ** 0.5)
-        return XF.LinearFn.apply(ctxl, self.out.weight, self.out.bias, True)
+        return XF.LinearFn.apply(ctxl, self.out.weight, self.out.bias, True, _p(self, self.proj_dropout))
 
 
 class Block(nn.Module):
@@ -69,11 +74,12 @@ class Block(nn.Module):
 
     def forward(self, x):
         a, f = self.multi_head, self.ffn
-        _no_train_dropout(self, a.attn_dropout.p, f.dropout.p)
+        _no_prob_dropout(self, a.attn_dropout)
         return XF.EncoderBlockFn.apply(
             x, self.attention_norm.weight, self.attention_norm.bias, a.query.weight, a.query.bias, a.key.weight, a.key.bias,
             a.value.weight, a.value.bias, a.out.weight, a.out.bias, self.ffn_norm.weight, self.ffn_norm.bias,
-            f.fc1.weight, f.fc1.bias, f.fc2.weight, f.fc2.bias, a.num_attention_heads, self.attention_norm.eps)
+            f.fc1.weight, f.fc1.bias, f.fc2.weight, f.fc2.bias, a.num_attention_heads, self.attention_norm.eps,
+            _p(self, a.proj_dropout), _p(self, f.dropout))
 
 
 class Encoder(nn.Module):

@@ -76,6 +76,29 @@ def invalidate_shadows():
 
 
 # ------------------------------------------------------------------------------------------
+# dropout: counter-based masks.  A site's mask is a pure function of (seed, element index), so the
+# backward pass regenerates it instead of storing it; seeds derive from torch's global seed and
+# a call counter (reproducible under torch.manual_seed, different at every call).
+# ------------------------------------------------------------------------------------------
+
+_DROP_CALLS = 0
+
+
+def drop_seeds(n):
+    global _DROP_CALLS
+    out = []
+    for _ in range(n):
+        _DROP_CALLS += 1
+        out.append(((torch.initial_seed() & 0xFFFFFFFF) * 0x9E3779B1 + _DROP_CALLS * 0x85EBCA77) & 0x7FFFFFFFFFFFFFFF)
+    return tuple(out)
+
+
+def _dp(p, seed):
+    """(p, seed) pair for the kernels, or None when dropout is off."""
+    return (p, seed) if p > 0.0 else None
+
+
+# ------------------------------------------------------------------------------------------
 # helpers
 # ------------------------------------------------------------------------------------------
 
@@ -106,15 +129,21 @@ def _skinny_split(m, n, k):
     return max(1, min(((k + 63) // 64) // 4, 96 // tiles))
 
 
-def _linear(x_b, w_s, *, bias=None, residual=None, act=ops.ACT_NONE, aux=None, out_dtype=torch.bfloat16, **kw):
+def _linear(x_b, w_s, *, bias=None, residual=None, act=ops.ACT_NONE, aux=None, out_dtype=torch.bfloat16, dropout=None, **kw):
     y = torch.empty(x_b.shape[0], w_s.shape[0], dtype=out_dtype, device=x_b.device)
-    return ops.gemm(ops.NT, x_b, w_s, y, bias=bias, residual=residual, act=act, aux=aux,
+    return ops.gemm(ops.NT, x_b, w_s, y, bias=bias, residual=residual, act=act, aux=aux, dropout=dropout,
                     split_k=_skinny_split(x_b.shape[0], w_s.shape[0], w_s.shape[1]), **kw)
 
 
-def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None, colsum=None):
+def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None, colsum=None, dropout=None):
     dx = torch.empty(dy_b.shape[0], w_s.shape[1], dtype=torch.bfloat16, device=dy_b.device)
-    return ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=colsum, split_k=_skinny_split(dy_b.shape[0], w_s.shape[1], w_s.shape[0]))
+    return ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=colsum, dropout=dropout,
+                    split_k=_skinny_split(dy_b.shape[0], w_s.shape[1], w_s.shape[0]))
+
+
+def _masked(t_b, p, seed):
+    """In-place dropout mask on a freshly produced bf16 gradient tensor (p == 0: untouched)."""
+    return ops.dropout(t_b, p, seed, out=t_b) if p > 0.0 else t_b
 
 
 def _zeros(n, ref):
@@ -132,20 +161,22 @@ def _f32c(t):
 # ------------------------------------------------------------------------------------------
 
 
-def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln2w, ln2b, w1_s, b1, w2_s, b2):
-    """x fp32 [B*N, d] -> (x2 fp32 [B*N, d], saved activations)."""
+def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln2w, ln2b, w1_s, b1, w2_s, b2, p_out=0.0, p_ffn=0.0, seeds=(0, 0, 0)):
+    """x fp32 [B*N, d] -> (x2 fp32 [B*N, d], saved activations).  Dropout sites (reference
+    model_cross.py:47,25,27 / model.py:177,114,116): after the out-projection (p_out), after GELU and
+    after the second FFN Linear (p_ffn) — all fused into the producing GEMM's epilogue."""
     h1, mu1, rs1 = ops.layernorm_fwd(x, ln1w, ln1b, eps)
     qkv = _linear(h1, wqkv_s, bias=bqkv)
     o, lse = ops.attn_fwd(qkv, B, N, H, scale)
-    x1 = _linear(o, wo_s, bias=bo, residual=x, out_dtype=torch.float32)
+    x1 = _linear(o, wo_s, bias=bo, residual=x, out_dtype=torch.float32, dropout=_dp(p_out, seeds[0]))
     h2, mu2, rs2 = ops.layernorm_fwd(x1, ln2w, ln2b, eps)
     z = torch.empty(x.shape[0], w1_s.shape[0], dtype=torch.bfloat16, device=x.device)
-    a = _linear(h2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z)
-    x2 = _linear(a, w2_s, bias=b2, residual=x1, out_dtype=torch.float32)
+    a = _linear(h2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z, dropout=_dp(p_ffn, seeds[1]))
+    x2 = _linear(a, w2_s, bias=b2, residual=x1, out_dtype=torch.float32, dropout=_dp(p_ffn, seeds[2]))
     return x2, (x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a)
 
 
-def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w, w1_s, w2_s, need_dx=True):
+def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w, w1_s, w2_s, p_out=0.0, p_ffn=0.0, seeds=(0, 0, 0)):
     """dy fp32 [B*N, d] -> (dx, grads dict).  Bias gradients cost no extra pass: b2 and bo fall out of the
     LN2 backward (column sums of its dres and dx), b1 out of the GELU' dgrad epilogue."""
     x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a = saved
@@ -153,13 +184,20 @@ def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w
     zero = torch.zeros(6 * d + f, dtype=torch.float32, device=x.device)   # every atomically-accumulated vector of this block
     g = dict(zip(("ln2w", "ln2b", "bo", "b2", "ln1w", "ln1b"), zero[:6 * d].split(d)))
     g["b1"] = zero[6 * d:]
-    dyb = ops.cast_bf16(dy)
+    dyb = _masked(ops.cast_bf16(dy), p_ffn, seeds[2])        # d(FFN out) = dy * mask
     # FFN
-    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"])
+    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"], dropout=_dp(p_ffn, seeds[1]))
     g["w2"] = _wgrad(dyb, a)
     dh2 = _dgrad(dz, w1_s)
     g["w1"] = _wgrad(dz, h2)
-    dx1, dx1b = ops.layernorm_bwd(dh2, x1, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy, want_bf16=True, dxsum=g["bo"], dressum=g["b2"])
+    # without dropout the two bias gradients are column sums LN2's backward produces anyway
+    dx1, dx1b = ops.layernorm_bwd(dh2, x1, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy, want_bf16=True,
+                                  dxsum=g["bo"] if p_out == 0.0 else None, dressum=g["b2"] if p_ffn == 0.0 else None)
+    if p_ffn > 0.0:
+        ops.colsum(dyb, out=g["b2"], accumulate=True)
+    if p_out > 0.0:
+        dx1b = _masked(dx1b, p_out, seeds[0])
+        ops.colsum(dx1b, out=g["bo"], accumulate=True)
     # attention
     do = _dgrad(dx1b, wo_s)
     g["wo"] = _wgrad(dx1b, o)
@@ -176,11 +214,14 @@ class SelfAttentionBlockFn(Function):
     """model_cross.SelfAttentionBlock: fused-qkv (no bias), eps 1e-5, scale dh**-0.5."""
 
     @staticmethod
-    def forward(ctx, x, ln1w, ln1b, wqkv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps):
+    def forward(ctx, x, ln1w, ln1b, wqkv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps, p=0.0):
         B, N, d = x.shape
         scale = (d // H) ** -0.5
         sh = (SHADOWS.get(wqkv), SHADOWS.get(wo), SHADOWS.get(w1), SHADOWS.get(w2))
-        x2, saved = block_forward(_f32c(x).reshape(B * N, d), B, N, H, eps, scale, ln1w, ln1b, sh[0], None, sh[1], bo, ln2w, ln2b, sh[2], b1, sh[3], b2)
+        seeds = drop_seeds(3) if p > 0.0 else (0, 0, 0)
+        x2, saved = block_forward(_f32c(x).reshape(B * N, d), B, N, H, eps, scale, ln1w, ln1b, sh[0], None, sh[1], bo, ln2w, ln2b, sh[2], b1, sh[3], b2,
+                                  p, p, seeds)
+        ctx.drop = (p, p, seeds)
         ctx.meta = (B, N, H, scale, x.dtype)
         ctx.save_for_backward(ln1w, ln2w, *sh, *saved)
         return x2.reshape(B, N, d)
@@ -189,20 +230,23 @@ class SelfAttentionBlockFn(Function):
     def backward(ctx, dy):
         B, N, H, scale, xdt = ctx.meta
         ln1w, ln2w, wqkv_s, wo_s, w1_s, w2_s, *saved = ctx.saved_tensors
-        dx, g = block_backward(_f32c(dy).reshape(B * N, -1), saved, B, N, H, scale, ln1w, wqkv_s, False, wo_s, ln2w, w1_s, w2_s)
-        return (dx.reshape(B, N, -1).to(xdt), g["ln1w"], g["ln1b"], g["wqkv"], g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None)
+        dx, g = block_backward(_f32c(dy).reshape(B * N, -1), saved, B, N, H, scale, ln1w, wqkv_s, False, wo_s, ln2w, w1_s, w2_s, *ctx.drop)
+        return (dx.reshape(B, N, -1).to(xdt), g["ln1w"], g["ln1b"], g["wqkv"], g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None)
 
 
 class EncoderBlockFn(Function):
     """model.Block: separate biased query/key/value, eps 1e-6, scores / sqrt(dh)."""
 
     @staticmethod
-    def forward(ctx, x, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps):
+    def forward(ctx, x, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps, p_out=0.0, p_ffn=0.0):
         B, N, d = x.shape
         scale = 1.0 / float(d // H) ** 0.5
         sh = (SHADOWS.get(wq, wk, wv), SHADOWS.get(wo), SHADOWS.get(w1), SHADOWS.get(w2))
         bqkv = torch.cat((bq, bk, bv)).detach()
-        x2, saved = block_forward(_f32c(x).reshape(B * N, d), B, N, H, eps, scale, ln1w, ln1b, sh[0], bqkv, sh[1], bo, ln2w, ln2b, sh[2], b1, sh[3], b2)
+        seeds = drop_seeds(3) if (p_out > 0.0 or p_ffn > 0.0) else (0, 0, 0)
+        x2, saved = block_forward(_f32c(x).reshape(B * N, d), B, N, H, eps, scale, ln1w, ln1b, sh[0], bqkv, sh[1], bo, ln2w, ln2b, sh[2], b1, sh[3], b2,
+                                  p_out, p_ffn, seeds)
+        ctx.drop = (p_out, p_ffn, seeds)
         ctx.meta = (B, N, H, scale, d, x.dtype)
         ctx.save_for_backward(ln1w, ln2w, *sh, *saved)
         return x2.reshape(B, N, d)
@@ -211,10 +255,10 @@ class EncoderBlockFn(Function):
     def backward(ctx, dy):
         B, N, H, scale, d, xdt = ctx.meta
         ln1w, ln2w, wqkv_s, wo_s, w1_s, w2_s, *saved = ctx.saved_tensors
-        dx, g = block_backward(_f32c(dy).reshape(B * N, -1), saved, B, N, H, scale, ln1w, wqkv_s, True, wo_s, ln2w, w1_s, w2_s)
+        dx, g = block_backward(_f32c(dy).reshape(B * N, -1), saved, B, N, H, scale, ln1w, wqkv_s, True, wo_s, ln2w, w1_s, w2_s, *ctx.drop)
         wq, wk, wv = g["wqkv"].split(d, dim=0)
         bq, bk, bv = g["bqkv"].split(d)
-        return (dx.reshape(B, N, -1).to(xdt), g["ln1w"], g["ln1b"], wq, bq, wk, bk, wv, bv, g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None)
+        return (dx.reshape(B, N, -1).to(xdt), g["ln1w"], g["ln1b"], wq, bq, wk, bk, wv, bv, g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------
@@ -222,7 +266,7 @@ class EncoderBlockFn(Function):
 # ------------------------------------------------------------------------------------------
 
 
-def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq_s, bq, wkv_s, bkv, wp_s, bp, ln2w, ln2b, w1_s, b1, w2_s, b2):
+def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq_s, bq, wkv_s, bkv, wp_s, bp, ln2w, ln2b, w1_s, b1, w2_s, b2, p=0.0, seeds=(0, 0, 0, 0)):
     """xi, xj fp32 [B*N, d] (cls taken from xi, patch tokens from xj) -> (y2 fp32 [B, d], saved)."""
     d = xi.shape[1]
     scale = (d // H) ** -0.5
@@ -230,17 +274,18 @@ def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq_s, bq, wkv_s, bkv, wp_s, 
     kv = _linear(hn, wkv_s, bias=bkv)
     hn0 = hn.reshape(B, N * d)[:, :d]                      # the B normed CLS rows, ld = N*d
     q = _linear(hn0, wq_s, bias=bq)
-    oc, p = ops.cls_xattn_fwd(q, kv, B, N, H, scale)
+    # dropout sites (model_cross.py:97,101,25,27): probabilities, proj output, after GELU, FFN output
+    oc, pr = ops.cls_xattn_fwd(q, kv, B, N, H, scale, dropout=(p, seeds[0]))
     cls_in = xi.reshape(B, N * d)[:, :d]                   # un-normed CLS rows (the residual, :112)
-    y = _linear(oc, wp_s, bias=bp, residual=cls_in, out_dtype=torch.float32)
+    y = _linear(oc, wp_s, bias=bp, residual=cls_in, out_dtype=torch.float32, dropout=_dp(p, seeds[1]))
     h2, mu2, rs2 = ops.layernorm_fwd(y, ln2w, ln2b, eps)
     z = torch.empty(B, w1_s.shape[0], dtype=torch.bfloat16, device=xi.device)
-    a = _linear(h2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z)
-    y2 = _linear(a, w2_s, bias=b2, residual=y, out_dtype=torch.float32)
-    return y2, (xi, xj, mu, rs, hn, kv, q, oc, p, y, mu2, rs2, h2, z, a)
+    a = _linear(h2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z, dropout=_dp(p, seeds[2]))
+    y2 = _linear(a, w2_s, bias=b2, residual=y, out_dtype=torch.float32, dropout=_dp(p, seeds[3]))
+    return y2, (xi, xj, mu, rs, hn, kv, q, oc, pr, y, mu2, rs2, h2, z, a)
 
 
-def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s):
+def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, pd=0.0, seeds=(0, 0, 0, 0)):
     """dy2 fp32 [B, d] -> (dcat fp32 [B*N, d] = grad of the normed concat input, dcls_res fp32 [B, d], grads)."""
     xi, xj, mu, rs, hn, kv, q, oc, p, y, mu2, rs2, h2, z, a = saved
     d, f = xi.shape[1], z.shape[1]
@@ -248,15 +293,21 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
     zero = torch.zeros(6 * d + f, dtype=torch.float32, device=xi.device)
     g = dict(zip(("ln2w", "ln2b", "bp", "b2", "ln1w", "ln1b"), zero[:6 * d].split(d)))
     g["b1"] = zero[6 * d:]
-    dyb = ops.cast_bf16(dy2)
-    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"])
+    dyb = _masked(ops.cast_bf16(dy2), pd, seeds[3])
+    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"], dropout=_dp(pd, seeds[2]))
     g["w2"] = _wgrad(dyb, a)
     dh2 = _dgrad(dz, w1_s)
     g["w1"] = _wgrad(dz, h2)
-    dy, dyb1 = ops.layernorm_bwd(dh2, y, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy2, want_bf16=True, dxsum=g["bp"], dressum=g["b2"])
+    nd = pd == 0.0
+    dy, dyb1 = ops.layernorm_bwd(dh2, y, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy2, want_bf16=True,
+                                 dxsum=g["bp"] if nd else None, dressum=g["b2"] if nd else None)
+    if not nd:
+        ops.colsum(dyb, out=g["b2"], accumulate=True)
+        dyb1 = _masked(dyb1, pd, seeds[1])
+        ops.colsum(dyb1, out=g["bp"], accumulate=True)
     doc = _dgrad(dyb1, wp_s)
     g["wp"] = _wgrad(dyb1, oc)
-    dq, dkv = ops.cls_xattn_bwd(q, kv, p, doc, B, N, H, scale)
+    dq, dkv = ops.cls_xattn_bwd(q, kv, p, doc, B, N, H, scale, dropout=(pd, seeds[0]))
     dqb = ops.cast_bf16(dq)
     dhn = _dgrad(dkv, wkv_s)                                # [B*N, d] bf16
     dhq = _dgrad(dqb, wq_s)                                 # [B, d] bf16: the query path reaches row 0 only
@@ -275,12 +326,14 @@ class CrossFusionFn(Function):
     """out_i = cat(CrossAttentionBlock(cat(cls_i, patches_j)), patches_i)  (model_cross.py:140-142)."""
 
     @staticmethod
-    def forward(ctx, xi, xj, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wp, bp, ln2w, ln2b, w1, b1, w2, b2, H, eps, concat):
+    def forward(ctx, xi, xj, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wp, bp, ln2w, ln2b, w1, b1, w2, b2, H, eps, concat, p=0.0):
         B, N, d = xi.shape
         sh = (SHADOWS.get(wq), SHADOWS.get(wk, wv), SHADOWS.get(wp), SHADOWS.get(w1), SHADOWS.get(w2))
         bkv = torch.cat((bk, bv)).detach()
         xi2, xj2 = _f32c(xi).reshape(B * N, d), _f32c(xj).reshape(B * N, d)
-        y2, saved = cross_forward(xi2, xj2, B, N, H, eps, ln1w, ln1b, sh[0], bq, sh[1], bkv, sh[2], bp, ln2w, ln2b, sh[3], b1, sh[4], b2)
+        seeds = drop_seeds(4) if p > 0.0 else (0, 0, 0, 0)
+        y2, saved = cross_forward(xi2, xj2, B, N, H, eps, ln1w, ln1b, sh[0], bq, sh[1], bkv, sh[2], bp, ln2w, ln2b, sh[3], b1, sh[4], b2, p, seeds)
+        ctx.drop = (p, seeds)
         ctx.meta = (B, N, H, d, concat)
         ctx.save_for_backward(ln1w, ln2w, *sh, *saved)
         if not concat:
@@ -295,7 +348,7 @@ class CrossFusionFn(Function):
         ln1w, ln2w, wq_s, wkv_s, wp_s, w1_s, w2_s, *saved = ctx.saved_tensors
         dout = _f32c(dout)
         dy2 = dout[:, 0].contiguous()
-        dcat, dcls_res, g = cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s)
+        dcat, dcls_res, g = cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, *ctx.drop)
         dcat = dcat.reshape(B, N, d)
         # cls row -> x_i (normed-concat path + the un-normed residual path); patch rows -> x_j
         if concat:
@@ -307,7 +360,7 @@ class CrossFusionFn(Function):
         dxj[:, 0] = 0
         wk, wv = g["wkv"].split(d, dim=0)
         bk, bv = g["bkv"].split(d)
-        return (dxi, dxj, g["ln1w"], g["ln1b"], g["wq"], g["bq"], wk, bk, wv, bv, g["wp"], g["bp"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None)
+        return (dxi, dxj, g["ln1w"], g["ln1b"], g["wq"], g["bq"], wk, bk, wv, bv, g["wp"], g["bp"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------
@@ -319,7 +372,7 @@ class PatchEmbedFn(Function):
     """img [B, M, 1, D, H, W] -> tokens fp32 [M, B, N, d] = cat(cls, patches W^T + b) + pos."""
 
     @staticmethod
-    def forward(ctx, img, w, b, cls, pos, patch):
+    def forward(ctx, img, w, b, cls, pos, patch, p=0.0):
         Bn, M = img.shape[0], img.shape[1]
         d, pd = w.shape
         patches = ops.patchify(img.contiguous(), patch, pad_cls_row=True).reshape(-1, pd)   # [M*B*N, pd], row 0 of each sample = 0
@@ -329,22 +382,27 @@ class PatchEmbedFn(Function):
         x = torch.empty(M * Bn * N, d, dtype=torch.float32, device=img.device)
         ops.gemm(ops.NT, patches, w_s, x, bias=b, residual=pos2, res_row_mod=N, res_row_off=0)
         ops.cls_row_fwd(cls.detach().reshape(d), pos2, x, M * Bn, N, d)
-        ctx.meta = (M, Bn, N, d)
+        seed = drop_seeds(1)[0] if p > 0.0 else 0
+        if p > 0.0:                       # self.dropout on the embedded tokens (model_cross.py:198)
+            ops.dropout(x, p, seed, out=x)
+        ctx.meta = (M, Bn, N, d, p, seed)
         ctx.save_for_backward(patches)
         return x.reshape(M, Bn, N, d)
 
     @staticmethod
     def backward(ctx, dx):
-        M, Bn, N, d = ctx.meta
+        M, Bn, N, d, p, seed = ctx.meta
         (patches,) = ctx.saved_tensors
         dx2 = _f32c(dx).reshape(M * Bn * N, d)
+        if p > 0.0:
+            dx2 = ops.dropout(dx2, p, seed)
         dxb = ops.cast_bf16(dx2)
         dW = _wgrad(dxb, patches)            # the zero CLS rows of `patches` drop the CLS-row gradients
         dpos = torch.zeros(N, d, dtype=torch.float32, device=dx.device)
         dcls = torch.zeros(d, dtype=torch.float32, device=dx.device)
         ops.embed_bwd(dx2, dpos, dcls, M * Bn, N, d)
         db = ops.colsum(dpos[1:])            # bias reaches the P patch rows of every sample
-        return None, dW, db, dcls.reshape(1, 1, d), dpos.reshape(1, N, d), None
+        return None, dW, db, dcls.reshape(1, 1, d), dpos.reshape(1, N, d), None, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -356,14 +414,18 @@ class HeadFn(Function):
     """logits_m = Linear(GELU(Linear(LN(x)[:, 0]))): only the CLS row of the final norm is used."""
 
     @staticmethod
-    def forward(ctx, x, lnw, lnb, w0, b0, w3, b3, eps):
+    def forward(ctx, x, lnw, lnb, w0, b0, w3, b3, eps, p=0.0):
         B, N, d = x.shape
         x2 = _f32c(x).reshape(B, N * d)[:, :d]              # CLS rows, ld = N*d
         h, mu, rs = ops.layernorm_fwd(x2, lnw, lnb, eps)
         w0_s = SHADOWS.get(w0)
         z = torch.empty(B, w0.shape[0], dtype=torch.bfloat16, device=x.device)
-        a = _linear(h, w0_s, bias=b0, act=ops.ACT_GELU, aux=z)
+        seeds = drop_seeds(2) if p > 0.0 else (0, 0)
+        a = _linear(h, w0_s, bias=b0, act=ops.ACT_GELU, aux=z, dropout=_dp(p, seeds[0]))   # mlp_head[m][2]
         logits = ops.small_linear_fwd(a, w3.detach(), b3.detach())
+        if p > 0.0:                                                                     # mlp_head[m][4]: dropout on the logits
+            ops.dropout(logits, p, seeds[1], out=logits)
+        ctx.drop = (p, seeds)
         ctx.meta = (B, N, d)
         ctx.save_for_backward(x2, mu, rs, h, z, a, lnw, w0_s, w3)
         return logits
@@ -372,9 +434,12 @@ class HeadFn(Function):
     def backward(ctx, dl):
         B, N, d = ctx.meta
         x2, mu, rs, h, z, a, lnw, w0_s, w3 = ctx.saved_tensors
+        p, seeds = ctx.drop
         dl = _f32c(dl)
+        if p > 0.0:
+            dl = ops.dropout(dl, p, seeds[1])
         dW3, db3 = torch.zeros_like(w3), _zeros(w3.shape[0], dl)
-        dz = ops.small_linear_bwd(dl, a, w3.detach(), dW3, db3, z=z)
+        dz = _masked(ops.small_linear_bwd(dl, a, w3.detach(), dW3, db3, z=z), p, seeds[0])
         dh = _dgrad(dz, w0_s)
         dW0 = _wgrad(dz, h)
         db0 = ops.colsum(dz)
@@ -382,7 +447,7 @@ class HeadFn(Function):
         dxc, _ = ops.layernorm_bwd(dh, x2, mu, rs, lnw, dg, dbeta)
         dx = torch.zeros(B, N, d, dtype=torch.float32, device=dl.device)
         dx[:, 0] = dxc
-        return dx, dg, dbeta, dW0, db0, dW3, db3, None
+        return dx, dg, dbeta, dW0, db0, dW3, db3, None, None
 
 
 class MeanCrossEntropyFn(Function):
@@ -442,45 +507,51 @@ class LinearFn(Function):
     """y = x W^T + b; x any float dtype (cast to bf16), y bf16 or fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, b, out_f32):
+    def forward(ctx, x, w, b, out_f32, p=0.0):
         x2 = _as_bf16_2d(x)
         w_s = SHADOWS.get(w)
-        y = _linear(x2, w_s, bias=b, out_dtype=torch.float32 if out_f32 else torch.bfloat16)
+        seed = drop_seeds(1)[0] if p > 0.0 else 0
+        y = _linear(x2, w_s, bias=b, out_dtype=torch.float32 if out_f32 else torch.bfloat16, dropout=_dp(p, seed))
         ctx.save_for_backward(x2, w_s)
-        ctx.meta = (x.shape, x.dtype, b is not None)
+        ctx.meta = (x.shape, x.dtype, b is not None, p, seed)
         return y.reshape(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, w_s = ctx.saved_tensors
-        shape, xdtype, has_b = ctx.meta
+        shape, xdtype, has_b, p, seed = ctx.meta
         dyb = _as_bf16_2d(dy)
+        if p > 0.0:
+            dyb = ops.dropout(dyb, p, seed)
         dx = _dgrad(dyb, w_s).reshape(shape)
-        return dx.to(xdtype), _wgrad(dyb, x2), (ops.colsum(dyb) if has_b else None), None
+        return dx.to(xdtype), _wgrad(dyb, x2), (ops.colsum(dyb) if has_b else None), None, None
 
 
 class FeedForwardFn(Function):
     """Linear -> exact GELU -> Linear (model_cross.py:19-31, model.py:107-122), fp32 out."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2):
+    def forward(ctx, x, w1, b1, w2, b2, p=0.0):
         x2 = _as_bf16_2d(x)
         w1_s, w2_s = SHADOWS.get(w1), SHADOWS.get(w2)
         z = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.bfloat16, device=x.device)
-        a = _linear(x2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z)
-        y = _linear(a, w2_s, bias=b2, out_dtype=torch.float32)
+        seeds = drop_seeds(2) if p > 0.0 else (0, 0)
+        a = _linear(x2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z, dropout=_dp(p, seeds[0]))
+        y = _linear(a, w2_s, bias=b2, out_dtype=torch.float32, dropout=_dp(p, seeds[1]))
         ctx.save_for_backward(x2, z, a, w1_s, w2_s)
-        ctx.meta = (x.shape, x.dtype)
+        ctx.meta = (x.shape, x.dtype, p, seeds)
         return y.reshape(*x.shape[:-1], w2.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         x2, z, a, w1_s, w2_s = ctx.saved_tensors
-        shape, xdtype = ctx.meta
+        shape, xdtype, p, seeds = ctx.meta
         dyb = _as_bf16_2d(dy)
-        dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z)
+        if p > 0.0:
+            dyb = ops.dropout(dyb, p, seeds[1])
+        dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, dropout=_dp(p, seeds[0]))
         dx = _dgrad(dz, w1_s).reshape(shape)
-        return dx.to(xdtype), _wgrad(dz, x2), ops.colsum(dz), _wgrad(dyb, a), ops.colsum(dyb)
+        return dx.to(xdtype), _wgrad(dz, x2), ops.colsum(dz), _wgrad(dyb, a), ops.colsum(dyb), None
 
 
 class AttentionCoreFn(Function):
@@ -507,17 +578,18 @@ class ClsAttentionCoreFn(Function):
     """one CLS query per (b, h) against N keys: q [B, d], kv [B, N, 2d] -> [B, d]."""
 
     @staticmethod
-    def forward(ctx, q, kv, H, scale):
+    def forward(ctx, q, kv, H, scale, pd=0.0):
         B, N, d2 = kv.shape
         qb, kvb = _as_bf16_2d(q), _as_bf16_2d(kv)
-        o, p = ops.cls_xattn_fwd(qb, kvb, B, N, H, scale)
+        seed = drop_seeds(1)[0] if pd > 0.0 else 0
+        o, p = ops.cls_xattn_fwd(qb, kvb, B, N, H, scale, dropout=(pd, seed))
         ctx.save_for_backward(qb, kvb, p)
-        ctx.meta = (B, N, H, scale, q.dtype, kv.dtype)
+        ctx.meta = (B, N, H, scale, q.dtype, kv.dtype, pd, seed)
         return o
 
     @staticmethod
     def backward(ctx, do):
         qb, kvb, p = ctx.saved_tensors
-        B, N, H, scale, qdt, kvdt = ctx.meta
-        dq, dkv = ops.cls_xattn_bwd(qb, kvb, p, _as_bf16_2d(do), B, N, H, scale)
-        return dq.to(qdt), dkv.reshape(B, N, -1).to(kvdt), None, None
+        B, N, H, scale, qdt, kvdt, pd, seed = ctx.meta
+        dq, dkv = ops.cls_xattn_bwd(qb, kvb, p, _as_bf16_2d(do), B, N, H, scale, dropout=(pd, seed))
+        return dq.to(qdt), dkv.reshape(B, N, -1).to(kvdt), None, None, None

@@ -60,7 +60,7 @@ def _rows2d(t):
 
 
 def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NONE, accumulate=False,
-         split_k=1, res_row_mod=0, res_row_off=0, out_seg=(0, 0, 0), M=None, N=None, K=None, colsum=None):
+         split_k=1, res_row_mod=0, res_row_off=0, out_seg=(0, 0, 0), M=None, N=None, K=None, colsum=None, dropout=None):
     """C = op(A) op(B) with the fused epilogue of include/xvit.h.  2-D tensors, or 3-D
     [batch, rows, cols] for a strided batch (all of A, B, C and optional bias 2-D / residual /
     aux 3-D then carry the batch in dim 0)."""
@@ -103,6 +103,8 @@ def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NON
     if colsum is not None:
         assert colsum.dtype == torch.float32
         a.colsum = _ptr(colsum)
+    if dropout is not None and dropout[0] > 0.0:   # (p, seed)
+        a.dropout_p, a.dropout_seed = float(dropout[0]), int(dropout[1])
     ws = None
     if split_k > 1:
         need = _lib.load().xvit_gemm_workspace_bytes(C.byref(a))
@@ -175,7 +177,7 @@ def attn_bwd(qkv, o, d_o, lse, B, N, H, scale):
     return dqkv
 
 
-def cls_xattn_fwd(q, kv, B, N, H, scale):
+def cls_xattn_fwd(q, kv, B, N, H, scale, dropout=(0.0, 0)):
     """q bf16 [B, d]; kv bf16 [B*N, 2d] (k | v) -> (o bf16 [B, d], p fp32 [B, H, N])."""
     d = q.shape[1]
     o = torch.empty(B, d, dtype=torch.bfloat16, device=q.device)
@@ -183,12 +185,12 @@ def cls_xattn_fwd(q, kv, B, N, H, scale):
     ld = _rows2d(kv)
     kp = kv.data_ptr()
     _run("cls_xattn_fwd", B * N * 2.0 * d * 2, "byte",
-         lambda: _lib.load().xvit_cls_xattn_fwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(o), d, _ptr(p), B, H, N, d // H, scale, _stream()),
-         "xvit_cls_xattn_fwd")
+         lambda: _lib.load().xvit_cls_xattn_fwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(o), d, _ptr(p), B, H, N, d // H, scale,
+                                                float(dropout[0]), int(dropout[1]), _stream()), "xvit_cls_xattn_fwd")
     return o, p
 
 
-def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale):
+def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale, dropout=(0.0, 0)):
     """-> (dq fp32 [B, d], dkv bf16 [B*N, 2d])."""
     d = q.shape[1]
     dq = torch.empty(B, d, dtype=torch.float32, device=q.device)
@@ -198,7 +200,8 @@ def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale):
     kp, gp = kv.data_ptr(), dkv.data_ptr()
     _run("cls_xattn_bwd", B * N * 2.0 * d * 2 * 2, "byte",
          lambda: _lib.load().xvit_cls_xattn_bwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(p), _ptr(d_o), _rows2d(d_o), _ptr(dq), d,
-                                                gp, gp + 2 * d, B, H, N, d // H, scale, _stream()), "xvit_cls_xattn_bwd")
+                                                gp, gp + 2 * d, B, H, N, d // H, scale, float(dropout[0]), int(dropout[1]), _stream()),
+         "xvit_cls_xattn_bwd")
     return dq, dkv
 
 

@@ -44,7 +44,7 @@ const char* xvit_last_error_string(void);
  *   layout NT: A[M,K] (k contiguous), B[N,K] (k contiguous)       y = x W^T      (forward)
  *   layout NN: A[M,K] (k contiguous), B[K,N] (n contiguous)       dx = dy W      (dgrad)
  *   layout TN: A stored [K,M] (m contiguous), B[K,N] (n contig.)  dW = dy^T x    (wgrad)
- * Epilogue, in this order: +bias[n]; act; +residual; row remap; store / accumulate.
+ * Epilogue, in this order: +bias[n]; act; dropout; +residual; row remap; store / accumulate.
  * ---------------------------------------------------------------------------------------- */
 enum { XVIT_GEMM_NT = 0, XVIT_GEMM_NN = 1, XVIT_GEMM_TN = 2 };
 enum { XVIT_ACT_NONE = 0,
@@ -76,6 +76,10 @@ typedef struct xvit_gemm_args {
   int64_t workspace_bytes;
   float* colsum;           /* optional fp32 [N]: colsum[n] += sum over rows of the stored C (bias gradient of the
                               producing Linear, e.g. dz of FeedForward); per-batch stride = stride_bias */
+  /* nn.Dropout fused after the activation: element (row, col) is kept iff hash(seed, row*N + col) >= p * 2^24
+     (the mask xvit_dropout applies to a contiguous [M, N] tensor with the same seed), scaled by 1/(1-p) */
+  float dropout_p; int32_t reserved2;
+  uint64_t dropout_seed;
 } xvit_gemm_args;
 
 int xvit_gemm(const xvit_gemm_args* args, xvit_stream_t stream);
@@ -126,10 +130,12 @@ int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t stride_b,
  * (saved for backward).  HBM-bound GEMV-style kernel.
  * ---------------------------------------------------------------------------------------- */
 int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t stride_b, int64_t stride_n, void* o,
-                       int64_t ldo, float* p, int B, int H, int N, int dh, float scale, xvit_stream_t stream);
+                       int64_t ldo, float* p, int B, int H, int N, int dh, float scale, float dropout_p, uint64_t dropout_seed,
+                       xvit_stream_t stream);
+/* dropout_p / dropout_seed: attn_drop on the probabilities (model_cross.py:97); p[] holds the pre-dropout values */
 int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t stride_b, int64_t stride_n, const float* p,
                        const void* d_o, int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, int B, int H, int N, int dh,
-                       float scale, xvit_stream_t stream);
+                       float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * 3-D patchify (model_cross.py:193): img [B, M, 1, D, H, W] (fp32 or bf16, contiguous) ->
