@@ -27,7 +27,7 @@ struct GemmParams {
 
 // ---- the fused epilogue, shared by both tile kernels and the split-K reduce kernel -------------
 // v: 4 consecutive output columns of one row (fp32 accumulators).  Returns the value stored.
-template <int ACT>
+template <int ACT, bool DROP = false>
 __device__ __forceinline__ f32x4 epilogue_apply(const GemmParams& p, f32x4 v, int row, int col, int64_t cb, const float* bias, const float* res,
                                                 bf16* aux) {
   if (bias) v += *(const f32x4*)(bias + col);
@@ -43,7 +43,7 @@ __device__ __forceinline__ f32x4 epilogue_apply(const GemmParams& p, f32x4 v, in
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(bf2f(z[e]));
   }
-  if (p.drop_p > 0.f) {   // mask keyed by (seed, batch-local element index): regenerated, never stored
+  if (DROP) {   // mask keyed by (seed, batch-local element index): regenerated, never stored
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
     const uint64_t idx = (uint64_t)(cb / (p.sC ? p.sC : 1)) * ((uint64_t)p.M * p.N) + (uint64_t)row * p.N + col;
 #pragma unroll
@@ -66,6 +66,11 @@ __device__ __forceinline__ f32x4 epilogue_apply(const GemmParams& p, f32x4 v, in
 }
 __device__ __forceinline__ f32x4 epilogue_apply_rt(const GemmParams& p, f32x4 v, int row, int col, int64_t cb, const float* bias, const float* res,
                                                    bf16* aux) {
+  if (p.drop_p > 0.f) {
+    if (p.act == XVIT_ACT_GELU) return epilogue_apply<XVIT_ACT_GELU, true>(p, v, row, col, cb, bias, res, aux);
+    if (p.act == XVIT_ACT_DGELU) return epilogue_apply<XVIT_ACT_DGELU, true>(p, v, row, col, cb, bias, res, aux);
+    return epilogue_apply<XVIT_ACT_NONE, true>(p, v, row, col, cb, bias, res, aux);
+  }
   if (p.act == XVIT_ACT_GELU) return epilogue_apply<XVIT_ACT_GELU>(p, v, row, col, cb, bias, res, aux);
   if (p.act == XVIT_ACT_DGELU) return epilogue_apply<XVIT_ACT_DGELU>(p, v, row, col, cb, bias, res, aux);
   return epilogue_apply<XVIT_ACT_NONE>(p, v, row, col, cb, bias, res, aux);
@@ -351,25 +356,25 @@ struct BigEpi {
   int row0, col0;
 };
 
-template <int ACT, int I, int J>
+template <int ACT, bool DROP, int I, int J>
 __device__ __forceinline__ void big_epi_one(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4], f32x4 (&cs)[4]) {
   const int row = e.row0 + I * 16, col = e.col0 + J * 16;
   if (row < p.M && col < p.N) {
     if (e.slab_tile) *(f32x4*)(e.slab_tile + (int64_t)row * p.N + col) = acc[I][J];   // split-K partial sums
-    else cs[J] += epilogue_apply<ACT>(p, acc[I][J], row, col, e.cb, e.bias, e.res, e.aux);
+    else cs[J] += epilogue_apply<ACT, DROP>(p, acc[I][J], row, col, e.cb, e.bias, e.res, e.aux);
   }
 }
-template <int ACT, int I>
+template <int ACT, bool DROP, int I>
 __device__ __forceinline__ void big_epi_row(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4], f32x4 (&cs)[4]) {
-  big_epi_one<ACT, I, 0>(p, e, acc, cs); big_epi_one<ACT, I, 1>(p, e, acc, cs); big_epi_one<ACT, I, 2>(p, e, acc, cs); big_epi_one<ACT, I, 3>(p, e, acc, cs);
+  big_epi_one<ACT, DROP, I, 0>(p, e, acc, cs); big_epi_one<ACT, DROP, I, 1>(p, e, acc, cs); big_epi_one<ACT, DROP, I, 2>(p, e, acc, cs); big_epi_one<ACT, DROP, I, 3>(p, e, acc, cs);
 }
-template <int ACT>
+template <int ACT, bool DROP>
 __device__ __forceinline__ void big_epilogue(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4], int lane) {
   f32x4 cs[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  big_epi_row<ACT, 0>(p, e, acc, cs); big_epi_row<ACT, 1>(p, e, acc, cs); big_epi_row<ACT, 2>(p, e, acc, cs); big_epi_row<ACT, 3>(p, e, acc, cs);
-  big_epi_row<ACT, 4>(p, e, acc, cs); big_epi_row<ACT, 5>(p, e, acc, cs); big_epi_row<ACT, 6>(p, e, acc, cs); big_epi_row<ACT, 7>(p, e, acc, cs);
+  big_epi_row<ACT, DROP, 0>(p, e, acc, cs); big_epi_row<ACT, DROP, 1>(p, e, acc, cs); big_epi_row<ACT, DROP, 2>(p, e, acc, cs); big_epi_row<ACT, DROP, 3>(p, e, acc, cs);
+  big_epi_row<ACT, DROP, 4>(p, e, acc, cs); big_epi_row<ACT, DROP, 5>(p, e, acc, cs); big_epi_row<ACT, DROP, 6>(p, e, acc, cs); big_epi_row<ACT, DROP, 7>(p, e, acc, cs);
   if (e.colsum) {  // this wave's 128 rows: 8 in-lane + the 16 lanes that share (lane >> 4); one atomic per column per wave
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -466,9 +471,13 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   e.row0 = m0 + wr * 128 + (lane & 15);
   e.col0 = n0 + wc * 64 + (lane >> 4) * 4;
   // one specialised, fully unrolled copy per activation: every acc[][] index is a compile-time constant
-  if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU>(p, e, acc, lane);
-  else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU>(p, e, acc, lane);
-  else big_epilogue<XVIT_ACT_NONE>(p, e, acc, lane);
+  if (p.drop_p > 0.f) {   // training-mode dropout: separate instantiations, so the p == 0 path carries none of that code
+    if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, true>(p, e, acc, lane);
+    else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, true>(p, e, acc, lane);
+    else big_epilogue<XVIT_ACT_NONE, true>(p, e, acc, lane);
+  } else if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, false>(p, e, acc, lane);
+  else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, false>(p, e, acc, lane);
+  else big_epilogue<XVIT_ACT_NONE, false>(p, e, acc, lane);
 }
 
 // split-K second pass: sum the partial tiles in a fixed order (bit-reproducible), then the full epilogue

@@ -7,7 +7,8 @@
 
 namespace xvit {
 
-constexpr int LN_WAVES = 4;
+constexpr int LN_WAVES = 8;    // forward: waves per block (rows are latency-bound per wave: keep many in flight per CU)
+constexpr int LNB_WAVES = 4;   // backward: 4-wave blocks, [4][2][d] LDS reduction buffer (24 KB at d = 768)
 
 template <int V>  // V float4 per lane: d <= 256*V
 __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x_alt, int64_t ldx,
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const float* __re
 }
 
 template <int V>
-__global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const bf16* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+__global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const bf16* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                                const float* __restrict__ x_alt, int64_t ldx, int seq_len,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ dres, int64_t lddres,
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const bf16* __res
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum,
                                                                float* __restrict__ dressum, int rows, int d) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* red = (float*)smem_raw;  // [LN_WAVES][4][d]
+  float* red = (float*)smem_raw;  // [LNB_WAVES][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d >> 2;
   const float inv_d = 1.0f / (float)d;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const bf16* __res
     sx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     sr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
+  for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
     const float* src = (x_alt && (row % seq_len) == 0) ? x_alt : x;
     const f32x4* xr = (const f32x4*)(src + (int64_t)row * ldx);
     const bf16* dyr = dy + (int64_t)row * lddy;
@@ -128,28 +129,29 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_bwd_kernel(const bf16* __res
       }
     }
   }
-  // cross-wave reduction of the column partials, then one atomic per column per block
+  // cross-wave reduction of the column partials through LDS in two rounds ([waves][2][d] each: dgamma|dbeta, then
+  // the optional sum(dx)|sum(dres)), one global atomic per column per block.  (LDS float atomics into a single
+  // accumulator were measured 2x slower: 8 waves hammer the same addresses.)
 #pragma unroll
-  for (int i = 0; i < V; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
-      *(f32x4*)(red + (wave * 4 + 0) * d + c * 4) = dg[i];
-      *(f32x4*)(red + (wave * 4 + 1) * d + c * 4) = db[i];
-      *(f32x4*)(red + (wave * 4 + 2) * d + c * 4) = sx[i];
-      *(f32x4*)(red + (wave * 4 + 3) * d + c * 4) = sr[i];
-    }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < d; c += blockDim.x) {
-    float a = 0.f, b = 0.f, x2 = 0.f, r2 = 0.f;
+  for (int round = 0; round < 2; ++round) {
+    if (round == 1 && !dxsum && !dressum) break;
+    if (round == 1) __syncthreads();
 #pragma unroll
-    for (int w = 0; w < LN_WAVES; ++w) {
-      a += red[(w * 4 + 0) * d + c]; b += red[(w * 4 + 1) * d + c]; x2 += red[(w * 4 + 2) * d + c]; r2 += red[(w * 4 + 3) * d + c];
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + i * 64;
+      if (c < nv) {
+        *(f32x4*)(red + (wave * 2 + 0) * d + c * 4) = round == 0 ? dg[i] : sx[i];
+        *(f32x4*)(red + (wave * 2 + 1) * d + c * 4) = round == 0 ? db[i] : sr[i];
+      }
     }
-    unsafeAtomicAdd(dgamma + c, a);
-    unsafeAtomicAdd(dbeta + c, b);
-    if (dxsum) unsafeAtomicAdd(dxsum + c, x2);
-    if (dressum) unsafeAtomicAdd(dressum + c, r2);
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += blockDim.x) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < LNB_WAVES; ++w) { a += red[(w * 2 + 0) * d + c]; b += red[(w * 2 + 1) * d + c]; }
+      if (round == 0) { unsafeAtomicAdd(dgamma + c, a); unsafeAtomicAdd(dbeta + c, b); }
+      else { if (dxsum) unsafeAtomicAdd(dxsum + c, a); if (dressum) unsafeAtomicAdd(dressum + c, b); }
+    }
   }
 }
 
@@ -171,7 +173,8 @@ extern "C" int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ld
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ln_grid(rows)), block(LN_WAVES * 64);
   bf16* yb = (bf16*)y;
-  if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, mean, rstd, rows, d);
+  if (d <= 768) hipLaunchKernelGGL((ln_fwd_kernel<3>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, mean, rstd, rows, d);
+  else if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, mean, rstd, rows, d);
   else hipLaunchKernelGGL((ln_fwd_kernel<16>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, mean, rstd, rows, d);
   return check_launch("xvit_layernorm_fwd");
 }
@@ -187,13 +190,15 @@ extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, 
   XVIT_REQUIRE(!x_alt || seq_len > 0, "xvit_layernorm_bwd: x_alt needs seq_len > 0");
   XVIT_REQUIRE(!dressum || dres, "xvit_layernorm_bwd: dressum needs dres");
   hipStream_t s = (hipStream_t)stream;
-  int g = ln_grid(rows);
-  if (g > 512) g = 512;  // every block adds its dgamma/dbeta partials to the SAME d addresses: more blocks = atomic contention (measured slower)
-  const dim3 grid(g), block(LN_WAVES * 64);
-  const size_t lds = (size_t)LN_WAVES * 4 * d * sizeof(float);
+  int g = (rows + LNB_WAVES - 1) / LNB_WAVES;
+  if (g > 768) g = 768;  // every block adds its dgamma/dbeta partials to the SAME d addresses: more blocks = atomic contention (measured slower)
+  const dim3 grid(g), block(LNB_WAVES * 64);
+  const size_t lds = (size_t)LNB_WAVES * 2 * d * sizeof(float);
   const bf16* dyb = (const bf16*)dy;
   bf16* dxbb = (bf16*)dxb;
-  if (d <= 1024)
+  if (d <= 768)
+    hipLaunchKernelGGL((ln_bwd_kernel<3>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, rows, d);
+  else if (d <= 1024)
     hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, rows, d);
   else
     hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, rows, d);

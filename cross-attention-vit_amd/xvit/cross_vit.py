@@ -223,7 +223,22 @@ class ModelCross(_Base):
         self.mlp_head = nn.ModuleList(_mlp_container(config, config.num_classes) for _ in range(M))
         self.initialize_model()
 
+    def _sync_flat_weights(self):
+        """Keep the weight matrices in one flat fp32 buffer + one flat bf16 operand copy (XF.FlatWeights);
+        re-cast the latter with a single launch whenever any weight changed since the last forward."""
+        grp = getattr(self, "_flat", None)
+        if grp is None or not grp.intact() or grp.params[0].device != self.pos_embedding.device:
+            if grp is not None:
+                XF.SHADOWS.detach(grp)
+            grp = XF.FlatWeights(list(self.parameters()))
+            object.__setattr__(self, "_flat", grp)
+            XF.SHADOWS.attach(grp)
+        grp.refresh(force=XF.SHADOWS.force)
+        XF.SHADOWS.force = False
+
     def forward(self, img, labels):
+        if self.pos_embedding.is_cuda and os.environ.get("XVIT_FLAT_WEIGHTS", "1") != "0":
+            self._sync_flat_weights()
         if img.shape[1] != self.num_modalities:
             raise ValueError(f"expected {self.num_modalities} modalities, got {img.shape[1]}")
         tokens = XF.PatchEmbedFn.apply(img, self.patch_to_embedding.weight, self.patch_to_embedding.bias,

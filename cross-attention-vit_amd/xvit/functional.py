@@ -29,6 +29,8 @@ class _ShadowCache:
     def __init__(self):
         self._map = {}
         self.casts = 0
+        self.groups = []    # FlatWeights of live models (weakly referenced through their owner module)
+        self.force = False
 
     @staticmethod
     def _cast(params):
@@ -45,6 +47,10 @@ class _ShadowCache:
 
     def get(self, *params):
         """bf16 copy of one parameter, or of several concatenated along dim 0."""
+        for grp in self.groups:
+            v = grp.lookup(params)
+            if v is not None:
+                return v
         self.casts += len(params)
         if not all(isinstance(p, torch.nn.Parameter) for p in params):
             self.casts += 0
@@ -63,6 +69,63 @@ class _ShadowCache:
 
     def invalidate(self):
         self._map.clear()
+        self.force = True   # flat groups re-cast at their owner's next forward
+
+    def attach(self, group):
+        self.groups = [g for g in self.groups if g.intact()] + [group]
+
+    def detach(self, group):
+        self.groups = [g for g in self.groups if g is not group]
+
+
+class FlatWeights:
+    """All 2-D weight matrices of one model as views into ONE fp32 buffer (p.data is re-pointed, the
+    Parameter objects, their names and their optimizer state are untouched) with a parallel bf16 buffer:
+    the per-step operand cast is a single launch over the flat buffer instead of one per matrix, and
+    row-concatenations of neighbours (wk|wv, query|key|value) are plain adjacent views."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.dim() == 2]
+        dev = self.params[0].device
+        offs, total = [], 0
+        for p in self.params:
+            offs.append(total)
+            total += (p.numel() + 7) // 8 * 8
+        self.flat32 = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat16 = torch.empty(total, dtype=torch.bfloat16, device=dev)
+        self.index, self.view16 = {}, []
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self.params, offs)):
+                v = self.flat32[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                self.view16.append(self.flat16[o:o + p.numel()].view(p.shape))
+                self.index[id(p)] = i
+        self.ptrs = [p.data_ptr() for p in self.params]
+        self.stamp = None
+
+    def intact(self):
+        """False once any parameter's storage was replaced (e.g. module.to(...))."""
+        return all(p.data_ptr() == q for p, q in zip(self.params, self.ptrs))
+
+    def refresh(self, force=False):
+        stamp = sum(p._version for p in self.params)
+        if force or stamp != self.stamp:
+            ops.cast_bf16(self.flat32, self.flat16)
+            self.stamp = stamp
+
+    def lookup(self, params):
+        """bf16 view for one member, or for members that are neighbours with nothing between them."""
+        idx = [self.index.get(id(p)) for p in params]
+        if any(i is None or self.params[i] is not p for i, p in zip(idx, params)):
+            return None
+        if len(idx) == 1:
+            return self.view16[idx[0]]
+        if any(b != a + 1 for a, b in zip(idx, idx[1:])) or any(self.params[i].numel() % 8 for i in idx[:-1]):
+            return None
+        first = self.view16[idx[0]]
+        rows = sum(self.params[i].shape[0] for i in idx)
+        return torch.as_strided(first, (rows,) + tuple(first.shape[1:]), first.stride(), first.storage_offset())
 
 
 SHADOWS = _ShadowCache()
