@@ -350,42 +350,87 @@ struct BigFrag {
   }
 };
 
+// ---- big-tile epilogue: branch-free, straight from the accumulators -----------------------------------
+// Every global access goes through a buffer resource with the out-of-range offset trick instead of a branch
+// (loads return 0, stores are dropped), so the 32 (row-tile, col-tile) bodies form one basic block and the
+// compiler batches the aux / residual loads instead of serialising 32 load->wait->compute->store rounds.
+typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2_t;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+constexpr uint32_t OOB = 0xFFFFFFF0u;
+
 struct BigEpi {
-  int64_t cb;
-  const float* bias; const float* res; bf16* aux; float* slab_tile; float* colsum;
+  __amdgpu_buffer_rsrc_t rc, raux, rres, rbias, rslab;
   int row0, col0;
+  bool has_res, has_aux, to_slab;
+  uint64_t drop_base;
 };
 
+// per-row byte offsets (32-bit: the host guarantees every addressed tensor stays below 2 GiB per batch)
+struct RowOff { uint32_t c, aux, res, slab; bool ok; uint32_t row; };
+
 template <int ACT, bool DROP, int I, int J>
-__device__ __forceinline__ void big_epi_one(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4], f32x4 (&cs)[4]) {
-  const int row = e.row0 + I * 16, col = e.col0 + J * 16;
-  if (row < p.M && col < p.N) {
-    if (e.slab_tile) *(f32x4*)(e.slab_tile + (int64_t)row * p.N + col) = acc[I][J];   // split-K partial sums
-    else cs[J] += epilogue_apply<ACT, DROP>(p, acc[I][J], row, col, e.cb, e.bias, e.res, e.aux);
+__device__ __forceinline__ void big_epi_one(const GemmParams& p, const BigEpi& e, const RowOff& r, const f32x4 (&acc)[8][4]) {
+  const uint32_t col = (uint32_t)(e.col0 + J * 16);
+  const bool ok = r.ok && col < (uint32_t)p.N;
+  f32x4 v = acc[I][J];
+  if (e.to_slab) {   // split-K partial sums, [M][N] fp32
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rslab, ok ? r.slab + col * 4 : OOB, 0, 0);
+    return;
+  }
+  v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rbias, col * 4, 0, 0));   // zero-size descriptor when there is no bias
+  if (ACT == XVIT_ACT_GELU) {
+    if (e.has_aux) {
+      bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, z), e.raux, ok ? r.aux + col * 2 : OOB, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
+  } else if (ACT == XVIT_ACT_DGELU) {
+    const bf16x4 z = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(e.raux, ok ? r.aux + col * 2 : OOB, 0, 0));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] *= dgelu_f(bf2f(z[c]));
+  }
+  if (DROP) {
+    const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+    const uint64_t idx = e.drop_base + (uint64_t)r.row * p.N + col;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (hash32(p.drop_seed, idx + c) & 0xFFFFFFu) >= thr ? v[c] * p.drop_inv : 0.f;
+  }
+  if (e.has_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rres, ok ? r.res + col * 4 : OOB, 0, 0));
+  if (p.c_f32) {
+    const uint32_t off = ok ? r.c + col * 4 : OOB;
+    if (p.accumulate) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rc, off, 0, 0));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rc, off, 0, 0);
+  } else {
+    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), e.rc, ok ? r.c + col * 2 : OOB, 0, 0);
   }
 }
 template <int ACT, bool DROP, int I>
-__device__ __forceinline__ void big_epi_row(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4], f32x4 (&cs)[4]) {
-  big_epi_one<ACT, DROP, I, 0>(p, e, acc, cs); big_epi_one<ACT, DROP, I, 1>(p, e, acc, cs); big_epi_one<ACT, DROP, I, 2>(p, e, acc, cs); big_epi_one<ACT, DROP, I, 3>(p, e, acc, cs);
+__device__ __forceinline__ void big_epi_row(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4]) {
+  RowOff r;
+  r.row = (uint32_t)(e.row0 + I * 16);
+  r.ok = r.row < (uint32_t)p.M;
+  const uint32_t rr = p.res_row_mod > 0 ? (uint32_t)p.res_row_off + r.row % (uint32_t)p.res_row_mod : r.row;
+  const uint32_t orow = p.seg_rows > 0 ? r.row + (r.row / (uint32_t)p.seg_rows) * (uint32_t)p.seg_skip + (uint32_t)p.row_off : r.row;
+  r.c = orow * (uint32_t)p.ldc * (p.c_f32 ? 4u : 2u);
+  r.aux = r.row * (uint32_t)p.ldaux * 2u;
+  r.res = rr * (uint32_t)p.ldr * 4u;
+  r.slab = r.row * (uint32_t)p.N * 4u;
+  big_epi_one<ACT, DROP, I, 0>(p, e, r, acc); big_epi_one<ACT, DROP, I, 1>(p, e, r, acc);
+  big_epi_one<ACT, DROP, I, 2>(p, e, r, acc); big_epi_one<ACT, DROP, I, 3>(p, e, r, acc);
 }
 template <int ACT, bool DROP>
-__device__ __forceinline__ void big_epilogue(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4], int lane) {
-  f32x4 cs[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) cs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  big_epi_row<ACT, DROP, 0>(p, e, acc, cs); big_epi_row<ACT, DROP, 1>(p, e, acc, cs); big_epi_row<ACT, DROP, 2>(p, e, acc, cs); big_epi_row<ACT, DROP, 3>(p, e, acc, cs);
-  big_epi_row<ACT, DROP, 4>(p, e, acc, cs); big_epi_row<ACT, DROP, 5>(p, e, acc, cs); big_epi_row<ACT, DROP, 6>(p, e, acc, cs); big_epi_row<ACT, DROP, 7>(p, e, acc, cs);
-  if (e.colsum) {  // this wave's 128 rows: 8 in-lane + the 16 lanes that share (lane >> 4); one atomic per column per wave
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float v = cs[j][c];
-        v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
-        const int col = e.col0 + j * 16 + c;
-        if ((lane & 15) == 0 && col < p.N) unsafeAtomicAdd(e.colsum + col, v);
-      }
-  }
+__device__ __forceinline__ void big_epilogue(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4]) {
+  // one row-tile (4 bodies, 4-8 loads in flight) per scheduling region
+  big_epi_row<ACT, DROP, 0>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
+  big_epi_row<ACT, DROP, 1>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
+  big_epi_row<ACT, DROP, 2>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
+  big_epi_row<ACT, DROP, 3>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
+  big_epi_row<ACT, DROP, 4>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
+  big_epi_row<ACT, DROP, 5>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
+  big_epi_row<ACT, DROP, 6>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
+  big_epi_row<ACT, DROP, 7>(p, e, acc);
 }
 
 template <bool A_KS, bool B_KS>
@@ -460,24 +505,32 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   }
 
   // ---------------- epilogue straight from the accumulators ------------------------------------
-  BigEpi e;
-  e.cb = batch * p.sC;
-  e.bias = p.bias ? p.bias + batch * p.sBias : nullptr;
-  e.res = p.res ? p.res + batch * p.sR : nullptr;
-  e.aux = p.aux ? p.aux + batch * p.sAux : nullptr;
   const int nbatch = gridDim.z / p.split_k;
-  e.slab_tile = p.slab ? p.slab + ((int64_t)split * nbatch + batch) * (int64_t)p.M * p.N : nullptr;
-  e.colsum = (p.colsum && !p.slab) ? p.colsum + batch * p.sBias : nullptr;
-  e.row0 = m0 + wr * 128 + (lane & 15);
-  e.col0 = n0 + wc * 64 + (lane >> 4) * 4;
-  // one specialised, fully unrolled copy per activation: every acc[][] index is a compile-time constant
-  if (p.drop_p > 0.f) {   // training-mode dropout: separate instantiations, so the p == 0 path carries none of that code
-    if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, true>(p, e, acc, lane);
-    else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, true>(p, e, acc, lane);
-    else big_epilogue<XVIT_ACT_NONE, true>(p, e, acc, lane);
-  } else if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, false>(p, e, acc, lane);
-  else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, false>(p, e, acc, lane);
-  else big_epilogue<XVIT_ACT_NONE, false>(p, e, acc, lane);
+  BigEpi e;
+  const int64_t celt = p.c_f32 ? 4 : 2;
+  e.rc = make_rsrc((const char*)p.C + batch * p.sC * celt, clamp_bytes(0x7FFFFFF0ll));
+  e.has_aux = p.aux != nullptr; e.has_res = p.res != nullptr; e.to_slab = p.slab != nullptr;
+  const bool has_bias = p.bias != nullptr;
+  e.raux = make_rsrc(e.has_aux ? (const void*)(p.aux + batch * p.sAux) : (const void*)p.C, e.has_aux ? 0x7FFFFFF0u : 0u);
+  e.rres = make_rsrc(e.has_res ? (const void*)(p.res + batch * p.sR) : (const void*)p.C, e.has_res ? 0x7FFFFFF0u : 0u);
+  e.rbias = make_rsrc(has_bias ? (const void*)(p.bias + batch * p.sBias) : (const void*)p.C, has_bias ? (uint32_t)(p.N * 4) : 0u);
+  e.rslab = make_rsrc(e.to_slab ? (const void*)(p.slab + ((int64_t)split * nbatch + batch) * (int64_t)p.M * p.N) : (const void*)p.C,
+                      e.to_slab ? clamp_bytes((int64_t)p.M * p.N * 4) : 0u);
+  // the epilogue's address arithmetic is loop-invariant: without this opaque dependency (placed AFTER the K loop)
+  // LLVM hoists ~100 registers of offsets above the MFMA loop and spills the accumulators
+  int pin = 0;
+  asm volatile("" : "+v"(pin));
+  e.row0 = m0 + wr * 128 + (lane & 15) + pin;
+  e.col0 = n0 + wc * 64 + (lane >> 4) * 4 + pin;
+  e.drop_base = (uint64_t)batch * ((uint64_t)p.M * p.N);
+  // one specialised, fully unrolled copy per (activation, dropout): every acc[][] index is a compile-time constant
+  if (p.drop_p > 0.f) {
+    if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, true>(p, e, acc);
+    else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, true>(p, e, acc);
+    else big_epilogue<XVIT_ACT_NONE, true>(p, e, acc);
+  } else if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, false>(p, e, acc);
+  else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, false>(p, e, acc);
+  else big_epilogue<XVIT_ACT_NONE, false>(p, e, acc);
 }
 
 // split-K second pass: sum the partial tiles in a fixed order (bit-reproducible), then the full epilogue
@@ -528,6 +581,12 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   const int64_t a_rows = a_ks ? a->K : a->M, b_rows = b_ks ? a->K : a->N;
   XVIT_REQUIRE(a_rows * a->lda * 2 < (1ll << 31) && b_rows * a->ldb * 2 < (1ll << 31), "xvit_gemm: an operand matrix exceeds 2 GiB (unsupported addressing range)");
   XVIT_REQUIRE(a->split_k >= 1, "xvit_gemm: split_k must be >= 1");
+  {
+    const int64_t out_rows = a->out_seg_rows > 0 ? (int64_t)a->M + (a->M / a->out_seg_rows + 1) * a->out_seg_skip + a->out_row_off : a->M;
+    XVIT_REQUIRE(out_rows * a->ldc * 4 < (1ll << 31) && (!a->aux || (int64_t)a->M * a->ldaux * 2 < (1ll << 31)) &&
+                     (!a->residual || (int64_t)a->M * a->ldr * 4 < (1ll << 31)),
+                 "xvit_gemm: C / aux / residual of one batch exceed 2 GiB (unsupported addressing range)");
+  }
   XVIT_REQUIRE(!(a->accumulate && a->c_dtype != XVIT_F32), "xvit_gemm: accumulate needs fp32 C");
   XVIT_REQUIRE(a->act != XVIT_ACT_DGELU || a->aux, "xvit_gemm: ACT_DGELU needs aux (pre-activation)");
   if (a->aux) XVIT_REQUIRE(a->ldaux % 4 == 0 && a->ldaux >= a->N && (reinterpret_cast<uintptr_t>(a->aux) & 7) == 0, "xvit_gemm: bad aux layout");
@@ -552,6 +611,7 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   p.seg_rows = a->out_seg_rows; p.seg_skip = a->out_seg_skip; p.row_off = a->out_row_off;
   p.slab = ws_need > 0 ? (float*)a->workspace : nullptr;
   p.colsum = a->colsum;
+  XVIT_REQUIRE(!a->colsum || !use_big_tile(a) || a->split_k > 1, "xvit_gemm: colsum is provided by the small-tile and split-K paths only (use xvit_colsum for large outputs)");
   XVIT_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "xvit_gemm: dropout_p must be in [0, 1)");
   p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
   hipStream_t s = (hipStream_t)stream;

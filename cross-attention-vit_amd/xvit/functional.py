@@ -199,9 +199,16 @@ def _linear(x_b, w_s, *, bias=None, residual=None, act=ops.ACT_NONE, aux=None, o
 
 
 def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None, colsum=None, dropout=None):
-    dx = torch.empty(dy_b.shape[0], w_s.shape[1], dtype=torch.bfloat16, device=dy_b.device)
-    return ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=colsum, dropout=dropout,
-                    split_k=_skinny_split(dy_b.shape[0], w_s.shape[1], w_s.shape[0]))
+    """dx = dy W (+ GELU' / dropout epilogue).  `colsum` (bias gradient of the Linear that produced dx's pre-image):
+    fused into the epilogue on the small / split-K paths, one HBM-bound xvit_colsum pass for large outputs."""
+    m, n, k = dy_b.shape[0], w_s.shape[1], w_s.shape[0]
+    dx = torch.empty(m, n, dtype=torch.bfloat16, device=dy_b.device)
+    split = _skinny_split(m, n, k)
+    fused = colsum is not None and (split > 1 or m < 256 or n < 256)
+    ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=colsum if fused else None, dropout=dropout, split_k=split)
+    if colsum is not None and not fused:
+        ops.colsum(dx, out=colsum, accumulate=True)
+    return dx
 
 
 def _masked(t_b, p, seed):
