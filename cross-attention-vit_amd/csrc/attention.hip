@@ -131,16 +131,20 @@ __device__ __forceinline__ void store_lane_rows(const f32x16 (&acc)[2], float mu
 }
 
 // ------------------------------------------------------------------------------------------
-// forward
+// forward.  Each wave owns QB blocks of 32 queries (QB = 2: 64 queries per wave, 256 per workgroup).  The
+// per-wave critical path of one tile (QK^T chain -> row max -> exp -> P.V chain) is latency-bound, so two
+// independent query blocks per wave double the instruction-level parallelism, and every K / V fragment
+// read from LDS feeds 2*QB MFMAs instead of 2.
 // ------------------------------------------------------------------------------------------
+template <int QB>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                           int64_t sb, int64_t sn, bf16* __restrict__ o, int64_t osb, int64_t osn,
                                                           float* __restrict__ lse, int H, int N, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;  // [2 stages][K image | V image]
+  XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;  // [FWD_NST stages][K image | V image]
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
   const int64_t off = (int64_t)b * sb + head * DH;
   const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
 
@@ -157,19 +161,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
       lk.issue(smem + st * 2 * IMG_BYTES, wave, st);
       lv.issue(smem + st * 2 * IMG_BYTES + IMG_BYTES, wave, st);
     }
-  bf16x8 qf[4];
-  load_lane_operand(qf, q + off, sn, q0, N, lane);   // one round trip together with the first ring tiles
-  settle(qf);                                        // (drains the prologue's DMAs too: fine, they are needed first)
+  bf16x8 qf[QB][4];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    load_lane_operand(qf[qb], q + off, sn, q0 + qb * 32, N, lane);   // one round trip together with the first ring tiles
+    settle(qf[qb]);                                                  // (drains the prologue's DMAs too: fine, they are needed first)
+  }
   ImgReader rd;
   rd.init(lane);
 
   const int h = lane >> 5;
   const float c = scale * LOG2E;
   const bool wave_active = q0 < N;   // wave-uniform
-  float m_run = -INFINITY, l_run = 0.f;
-  f32x16 oacc[2];
+  float m_run[QB], l_run[QB];
+  f32x16 oacc[QB][2];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { oacc[0][i] = 0.f; oacc[1][i] = 0.f; }
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY; l_run[qb] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oacc[qb][0][i] = 0.f; oacc[qb][1][i] = 0.f; }
+  }
 
   int stage = 0;
   for (int t = 0; t < ntiles; ++t) {
@@ -186,85 +197,103 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     const XVIT_LDS char* vimg = kimg + IMG_BYTES;
     stage = stage + 1 == FWD_NST ? 0 : stage + 1;
 
-    if (!wave_active) continue;   // this wave's 32 queries are all past N: keep moving tiles and barriers, skip the math
+    if (!wave_active) continue;   // this wave's queries are all past N: keep moving tiles and barriers, skip the math
     // keys of this tile past N: with <= 32 valid keys the second 32-key block is skipped entirely
     const int valid = N - t * TILE_ROWS;
     const bool two = valid > 32;
 
-    // S^T[key][query] = K Q^T
-    f32x16 s[2];
+    // S^T[key][query] = K Q^T: every K fragment is read once and used by all QB query blocks
+    f32x16 s[QB][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s[0][i] = 0.f; s[1][i] = -INFINITY; }
+    for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, 0, ks), qf[ks], s[0], 0, 0, 0);
+      for (int i = 0; i < 16; ++i) { s[qb][0][i] = 0.f; s[qb][1][i] = two ? 0.f : -INFINITY; }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 kf = rd.row_frag(kimg, 0, ks);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) s[qb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb][0], 0, 0, 0);
+    }
     if (two) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[1][i] = 0.f;
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = rd.row_frag(kimg, 1, ks);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, 1, ks), qf[ks], s[1], 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb) s[qb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb][1], 0, 0, 0);
+      }
     }
     if (valid < TILE_ROWS) {  // mask the keys past N
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
+      for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (kb * 32 + acc_row(i, h) >= valid) s[kb][i] = -INFINITY;
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (kb * 32 + acc_row(i, h) >= valid) s[qb][kb][i] = -INFINITY;
     }
-    // online softmax; the query is this lane's column, split over the two lane halves
-    float mx = s[0][0];
+    // online softmax per query block; the query is this lane's column, split over the two lane halves
 #pragma unroll
-    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[0][i]);
-    if (two) {
+    for (int qb = 0; qb < QB; ++qb) {
+      float mx = s[qb][0][0];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[1][i]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (__any(mx > m_run)) {   // some row's running max moved: rescale (otherwise alpha == 1 exactly, skip the pass)
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
-      l_run *= alpha;
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, s[qb][0][i]);
+      if (two) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { oacc[0][i] *= alpha; oacc[1][i] *= alpha; }
-    }
-    const float mc = m_run * c;
-    float psum = 0.f;
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[qb][1][i]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      if (__any(mx > m_run[qb])) {   // some row's running max moved: rescale (otherwise alpha == 1 exactly, skip the pass)
+        const float m_new = fmaxf(m_run[qb], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+        m_run[qb] = m_new;
+        l_run[qb] *= alpha;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const float pv = __builtin_amdgcn_exp2f(fmaf(s[0][i], c, -mc));
-      s[0][i] = pv;
-      psum += pv;
-    }
-    if (two) {
+        for (int i = 0; i < 16; ++i) { oacc[qb][0][i] *= alpha; oacc[qb][1][i] *= alpha; }
+      }
+      const float mc = m_run[qb] * c;
+      float psum = 0.f;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[1][i], c, -mc));
-        s[1][i] = pv;
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[qb][0][i], c, -mc));
+        s[qb][0][i] = pv;
         psum += pv;
       }
-    }
-    l_run += psum;
-    // O^T[d][query] += V^T P^T
+      if (two) {
 #pragma unroll
-    for (int ss = 0; ss < 2; ++ss) {
-      const bf16x8 pf = acc_frag(s[0], ss);
-#pragma unroll
-      for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(vimg, db, 0, ss), pf, oacc[db], 0, 0, 0);
+        for (int i = 0; i < 16; ++i) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[qb][1][i], c, -mc));
+          s[qb][1][i] = pv;
+          psum += pv;
+        }
+      }
+      l_run[qb] += psum;
     }
-    if (two) {
+    // O^T[d][query] += V^T P^T: every V fragment is read once and used by all QB query blocks
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb == 1 && !two) break;
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        const bf16x8 pf = acc_frag(s[1], ss);
+        bf16x8 pf[QB];
 #pragma unroll
-        for (int db = 0; db < 2; ++db) oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(vimg, db, 1, ss), pf, oacc[db], 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb) pf[qb] = acc_frag(s[qb][kb], ss);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const bf16x8 vf = rd.tr_frag(vimg, db, kb, ss);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) oacc[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb], oacc[qb][db], 0, 0, 0);
+        }
       }
     }
   }
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const int qrow = q0 + (lane & 31);
-  const bool valid = qrow < N;
-  if (valid && h == 0) lse[((int64_t)b * H + head) * N + qrow] = m_run * scale + __logf(l_tot);
-  store_lane_rows(oacc, 1.0f / l_tot, o + (int64_t)b * osb + head * DH, osn, qrow, valid, lane);
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    const int qrow = q0 + qb * 32 + (lane & 31);
+    const bool valid = qrow < N;
+    if (valid && h == 0) lse[((int64_t)b * H + head) * N + qrow] = m_run[qb] * scale + __logf(l_tot);
+    store_lane_rows(oacc[qb], 1.0f / l_tot, o + (int64_t)b * osb + head * DH, osn, qrow, valid, lane);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -489,8 +518,10 @@ extern "C" int xvit_attn_fwd(const void* q, const void* k, const void* v, int64_
                              int B, int H, int N, int dh, float scale, xvit_stream_t stream) {
   XVIT_REQUIRE(q && k && v && o && lse, "xvit_attn_fwd: null pointer");
   if (int e = attn_check("xvit_attn_fwd", B, H, N, dh, sb, sn, osb, osn)) return e;
+  // QB = 1 (32 queries per wave).  QB = 2 was measured: identical throughput at N = 512..4097 (the loop is bound by
+  // softmax VALU issue, 12.4 VALU per MFMA at d_h = 64 — not by LDS reads or per-wave ILP) and worse at small batch.
   const dim3 grid((N + 127) / 128, H, B), block(256);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, FWD_NST * 2 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+  hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, FWD_NST * 2 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
                      (bf16*)o, osb, osn, lse, H, N, scale);
   return check_launch("xvit_attn_fwd");
 }
