@@ -111,6 +111,8 @@ __device__ __forceinline__ void settle(bf16x8 (&f)[4]) {
   }
 }
 
+#define ZERO16 (f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f})
+
 // element index inside a 32-row accumulator block held in register i by lane half h
 __device__ __forceinline__ int acc_row(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
 
@@ -205,22 +207,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict
     // S^T[key][query] = K Q^T: every K fragment is read once and used by all QB query blocks
     f32x16 s[QB][2];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { s[qb][0][i] = 0.f; s[qb][1][i] = two ? 0.f : -INFINITY; }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {   // the first MFMA of each chain takes a literal-zero accumulator: no v_mov initialisation
       const bf16x8 kf = rd.row_frag(kimg, 0, ks);
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) s[qb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb][0], 0, 0, 0);
+      for (int qb = 0; qb < QB; ++qb) s[qb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? ZERO16 : s[qb][0], 0, 0, 0);
     }
     if (two) {
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const bf16x8 kf = rd.row_frag(kimg, 1, ks);
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb) s[qb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], s[qb][1], 0, 0, 0);
+        for (int qb = 0; qb < QB; ++qb) s[qb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? ZERO16 : s[qb][1], 0, 0, 0);
       }
+    } else {
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[qb][1][i] = -INFINITY;
     }
     if (valid < TILE_ROWS) {  // mask the keys past N
 #pragma unroll
@@ -375,11 +378,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
       if (kb >= nkb) break;
       f32x16 s, dp;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, kb, ks), qf[ks], ks == 0 ? ZERO16 : s, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, kb, ks), qf[ks], s, 0, 0, 0);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(vimg, kb, ks), dof[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(vimg, kb, ks), dof[ks], ks == 0 ? ZERO16 : dp, 0, 0, 0);
       // keys past N have K = V = 0 (zero-filled by the DMA), so they add nothing to dQ
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -466,13 +467,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
     for (int qb = 0; qb < 2; ++qb) {
       if (qb >= nqb) break;
       f32x16 s, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
       // S[query][key] = Q K^T ; dP[query][key] = dO V^T   (key on the lane)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(qimg, qb, ks), kf[ks], s, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(qimg, qb, ks), kf[ks], ks == 0 ? ZERO16 : s, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(doimg, qb, ks), vf[ks], dp, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(doimg, qb, ks), vf[ks], ks == 0 ? ZERO16 : dp, 0, 0, 0);
       f32x16 pr;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
