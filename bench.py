@@ -33,6 +33,11 @@ sys.path.insert(0, os.path.join(ROOT, "cross-attention-vit_amd"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# HBM bytes per launch of the dominant kernel family, from the rocprofv3 --pmc passes committed under profiles/
+# (FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE), averaged over the family's launches
+# of one step at the default batch.  Filled in from profiles/r01_pmc_traffic.md; None = not measured.
+TRAFFIC = {"gemm_big_nt": 2.87e8, "gemm_big_nn": 2.18e8, "gemm_big_tn+splitk": 3.10e8}   # profiles/r01_b_summary.md
+
 MFMA_PEAK_TF = 2516.0   # bf16 dense, MI355X_MICROARCH.md: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0   # HBM3E spec
 
@@ -114,8 +119,12 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape GEMM table on stderr (diagnostic)")
+    ap.add_argument("--single-stream", action="store_true", help="run the modality branches on one stream (used for the rocprof "
+                    "summary under profiles/, so per-kernel durations are not stretched by a concurrently running kernel)")
     args = ap.parse_args()
 
+    if args.single_stream:
+        os.environ["XVIT_STREAMS"] = "0"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,11 +210,21 @@ def main():
 
     # ---- per-kernel pricing with HIP events on the launch stream (rank 0) --------------------
     if rank == 0 and args.profile_steps > 0:
+        # kernels are priced one at a time: the two modality streams are merged for these extra steps, otherwise
+        # concurrently running kernels stretch each other's event brackets (the timed region above keeps them)
+        prev_streams = os.environ.get("XVIT_STREAMS")
+        os.environ["XVIT_STREAMS"] = "0"
+        step()
+        torch.cuda.synchronize(dev)
         ops.PROFILE, ops.PROFILE_SHAPES = [], args.detail
         for _ in range(args.profile_steps):
             step()
         torch.cuda.synchronize(dev)
         rec, ops.PROFILE = ops.PROFILE, None
+        if prev_streams is None:
+            os.environ.pop("XVIT_STREAMS")
+        else:
+            os.environ["XVIT_STREAMS"] = prev_streams
         if args.detail:
             det = {}
             for name, work, kind, s, e in rec:
@@ -233,9 +252,12 @@ def main():
             else:
                 k.update(bound="hbm", achieved=round(rate / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(rate / 1e9 / HBM_PEAK_GBS, 4))
             kernels[name] = k
-        dom = next(iter(kernels))
+        dom = next(k for k in kernels if "+splitk" not in k)   # a family that is exactly one kernel symbol
         out["roofline"] = {"kernel": dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")},
-                           "avg_launch_us": kernels[dom]["avg_us"], "traffic": None}
+                           "avg_launch_us": kernels[dom]["avg_us"], "traffic": TRAFFIC.get(dom),
+                           "note": "family with the largest share of step time; algorithmic FLOPs of all its launches / their summed duration "
+                                   "(HIP events on the launch stream, modality streams merged while pricing); traffic = HBM bytes per launch "
+                                   "from rocprofv3 PMC passes (profiles/), FETCH_SIZE doubled per the gfx950 note"}
         out["kernels"] = kernels
         # the north-star's attention target, stated separately
         if "attn_fwd" in kernels:

@@ -111,7 +111,9 @@ def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NON
         if need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=C_out.device)
             a.workspace, a.workspace_bytes = _ptr(ws), need
-    tag = ("gemm_nt", "gemm_nn", "gemm_tn")[layout]
+    # one family per kernel symbol: gemm_big_kernel<..> (M, N >= 256) vs gemm_kernel<..>; "+splitk" brackets also
+    # contain the splitk_epilogue_kernel launch that follows
+    tag = ("gemm_big_" if (a.M >= 256 and a.N >= 256) else "gemm_small_") + ("nt", "nn", "tn")[layout] + ("+splitk" if split_k > 1 else "")
     if PROFILE is not None and PROFILE_SHAPES:
         epi = ("+b" if bias is not None else "") + ("+gelu" if act == ACT_GELU else "+dgelu" if act == ACT_DGELU else "") + ("+res" if residual is not None else "")
         tag += f"[{a.M}x{a.N}x{a.K}{epi}{'' if a.c_dtype == BF16 else ',f32'}{',s%d' % split_k if split_k > 1 else ''}]"
