@@ -139,7 +139,7 @@ __device__ __forceinline__ void store_lane_rows(const f32x16 (&acc)[2], float mu
 // read from LDS feeds 2*QB MFMAs instead of 2.
 // ------------------------------------------------------------------------------------------
 template <int QB>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
+__global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                           int64_t sb, int64_t sn, bf16* __restrict__ o, int64_t osb, int64_t osn,
                                                           float* __restrict__ lse, int H, int N, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];

@@ -11,10 +11,10 @@ namespace xvit {
 // ------------------------------------------------------------------------------------------
 template <typename T, int VEC>
 __global__ void patchify_kernel(const T* __restrict__ img, bf16* __restrict__ out, int B, int M, int D, int H, int W, int dp, int hp, int wp,
-                                int pad, int64_t total_vec) {
+                                int64_t stride_b, int64_t stride_m, int row_off, int64_t total_vec) {
   const int Wv = W / VEC;
   const int Dn = D / dp, Wn = W / wp;
-  const int P = Dn * (H / hp) * Wn, pd = dp * hp * wp;
+  const int pd = dp * hp * wp;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total_vec; idx += (int64_t)gridDim.x * blockDim.x) {
     const int wv = (int)(idx % Wv);
     int64_t r = idx / Wv;
@@ -28,7 +28,7 @@ __global__ void patchify_kernel(const T* __restrict__ img, bf16* __restrict__ ou
     const int d = dd / dp, p1 = dd - d * dp;
     const int t = (h * Wn + w) * Dn + d;
     const int f = (p1 * hp + p2) * wp + p3;
-    bf16* dst = out + ((int64_t)(m * B + b) * (P + pad) + t + pad) * pd + f;
+    bf16* dst = out + ((int64_t)b * stride_b + (int64_t)m * stride_m + t + row_off) * pd + f;
     const T* src = img + idx * VEC;
     if constexpr (VEC == 8) {
       bf16x8 o;
@@ -217,29 +217,29 @@ static int grid_for(int64_t work, int block) {
 }
 
 extern "C" int xvit_patchify(const void* img, int img_dtype, void* out, int B, int M, int D, int H, int W, int dp, int hp, int wp,
-                             int pad, xvit_stream_t stream) {
+                             int64_t stride_b, int64_t stride_m, int row_off, int zero_rows, int64_t zero_row_stride, xvit_stream_t stream) {
   XVIT_REQUIRE(img && out, "xvit_patchify: null pointer");
   XVIT_REQUIRE(B > 0 && M > 0 && D > 0 && H > 0 && W > 0 && dp > 0 && hp > 0 && wp > 0, "xvit_patchify: bad sizes");
   XVIT_REQUIRE(D % dp == 0 && H % hp == 0 && W % wp == 0, "xvit_patchify: image dimensions must be divisible by the patch size");
   XVIT_REQUIRE(img_dtype == XVIT_F32 || img_dtype == XVIT_BF16, "xvit_patchify: bad dtype");
-  XVIT_REQUIRE(pad == 0 || pad == 1, "xvit_patchify: pad_cls_row must be 0 or 1");
-  XVIT_REQUIRE(pad == 0 || (dp * hp * wp) % 8 == 0, "xvit_patchify: pad_cls_row needs patch_dim %% 8 == 0");
+  XVIT_REQUIRE(stride_b > 0 && stride_m > 0 && row_off >= 0 && zero_rows >= 0, "xvit_patchify: bad output placement");
+  XVIT_REQUIRE(zero_rows == 0 || (dp * hp * wp) % 8 == 0, "xvit_patchify: zero rows need patch_dim %% 8 == 0");
   const int64_t total = (int64_t)B * M * D * H * W;
   hipStream_t s = (hipStream_t)stream;
   const bool vec = (wp % 8 == 0) && ((reinterpret_cast<uintptr_t>(img) & 31) == 0);
   bf16* o = (bf16*)out;
   if (vec) {
     const int64_t tv = total / 8;
-    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, pad, tv);
-    else hipLaunchKernelGGL((patchify_kernel<bf16, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, pad, tv);
+    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, stride_b, stride_m, row_off, tv);
+    else hipLaunchKernelGGL((patchify_kernel<bf16, 8>), dim3(grid_for(tv, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, stride_b, stride_m, row_off, tv);
   } else {
-    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, pad, total);
-    else hipLaunchKernelGGL((patchify_kernel<bf16, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, pad, total);
+    if (img_dtype == XVIT_F32) hipLaunchKernelGGL((patchify_kernel<float, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const float*)img, o, B, M, D, H, W, dp, hp, wp, stride_b, stride_m, row_off, total);
+    else hipLaunchKernelGGL((patchify_kernel<bf16, 1>), dim3(grid_for(total, 256)), dim3(256), 0, s, (const bf16*)img, o, B, M, D, H, W, dp, hp, wp, stride_b, stride_m, row_off, total);
   }
-  if (pad) {
-    const int pd = dp * hp * wp, P = (D / dp) * (H / hp) * (W / wp);
-    const int64_t work = (int64_t)B * M * (pd / 8);
-    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, o, B * M, (int64_t)(P + 1) * pd, pd);
+  if (zero_rows > 0) {
+    const int pd = dp * hp * wp;
+    const int64_t work = (int64_t)zero_rows * (pd / 8);
+    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, o, zero_rows, zero_row_stride * pd, pd);
   }
   return check_launch("xvit_patchify");
 }

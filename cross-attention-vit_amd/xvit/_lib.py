@@ -34,7 +34,7 @@ SIGNATURES = {
     "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "xvit_cls_xattn_fwd": [vp, i64, vp, vp, i64, i64, vp, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
-    "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, i32, i64, vp],
     "xvit_cls_row_fwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_embed_bwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_cast_f32_bf16": [vp, vp, i64, vp],

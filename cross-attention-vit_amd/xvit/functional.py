@@ -442,10 +442,14 @@ class PatchEmbedFn(Function):
     """img [B, M, 1, D, H, W] -> tokens fp32 [M, B, N, d] = cat(cls, patches W^T + b) + pos."""
 
     @staticmethod
-    def forward(ctx, img, w, b, cls, pos, patch, p=0.0):
+    def forward(ctx, img, w, b, cls, pos, patch, p=0.0, concat=False):
         Bn, M = img.shape[0], img.shape[1]
         d, pd = w.shape
-        patches = ops.patchify(img.contiguous(), patch, pad_cls_row=True).reshape(-1, pd)   # [M*B*N, pd], row 0 of each sample = 0
+        if concat:   # ModelVIT (modelv3.py:123-137): one sequence per sample, cls + the patches of every modality
+            patches = ops.patchify(img.contiguous(), patch, concat=True)                    # [B*(M*P+1), pd]
+            M = 1
+        else:        # ModelCross (model_cross.py:191-199): one sequence per (modality, sample)
+            patches = ops.patchify(img.contiguous(), patch, pad_cls_row=True).reshape(-1, pd)   # [M*B*N, pd], row 0 of each sample = 0
         N = patches.shape[0] // (M * Bn)
         w_s = SHADOWS.get(w)
         pos2 = pos.detach().reshape(N, d)
@@ -457,7 +461,7 @@ class PatchEmbedFn(Function):
             ops.dropout(x, p, seed, out=x)
         ctx.meta = (M, Bn, N, d, p, seed)
         ctx.save_for_backward(patches)
-        return x.reshape(M, Bn, N, d)
+        return x.reshape(Bn, N, d) if concat else x.reshape(M, Bn, N, d)
 
     @staticmethod
     def backward(ctx, dx):
@@ -472,7 +476,7 @@ class PatchEmbedFn(Function):
         dcls = torch.zeros(d, dtype=torch.float32, device=dx.device)
         ops.embed_bwd(dx2, dpos, dcls, M * Bn, N, d)
         db = ops.colsum(dpos[1:])            # bias reaches the P patch rows of every sample
-        return None, dW, db, dcls.reshape(1, 1, d), dpos.reshape(1, N, d), None, None
+        return None, dW, db, dcls.reshape(1, 1, d), dpos.reshape(1, N, d), None, None, None
 
 
 # ------------------------------------------------------------------------------------------

@@ -207,16 +207,25 @@ def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale, dropout=(0.0, 0)):
     return dq, dkv
 
 
-def patchify(img, patch, pad_cls_row=False):
-    """img [B, M, 1, D, H, W] fp32|bf16 contiguous -> patches bf16 [M, B*(P+pad), pd]."""
+def patchify(img, patch, pad_cls_row=False, concat=False):
+    """img [B, M, 1, D, H, W] fp32|bf16 contiguous -> bf16 patch rows.
+      default            [M, B*P, pd]           per modality, no padding
+      pad_cls_row        [M, B*(P+1), pd]       per modality, a zero row in front of every sample (ModelCross)
+      concat             [B*(M*P+1), pd]        all modalities of a sample in one sequence behind one zero row (ModelVIT)"""
     assert img.dim() == 6 and img.shape[2] == 1 and img.is_contiguous()
     B, M, _, D, H, W = img.shape
     dp, hp, wp = patch
     P, pd = (D // dp) * (H // hp) * (W // wp), dp * hp * wp
-    pad = int(bool(pad_cls_row))
-    out = torch.empty(M, B * (P + pad), pd, dtype=torch.bfloat16, device=img.device)
+    if concat:
+        rows = M * P + 1
+        out = torch.empty(B * rows, pd, dtype=torch.bfloat16, device=img.device)
+        place = (rows, P, 1, B, rows)
+    else:
+        pad = int(bool(pad_cls_row))
+        out = torch.empty(M, B * (P + pad), pd, dtype=torch.bfloat16, device=img.device)
+        place = (P + pad, B * (P + pad), pad, M * B if pad else 0, P + pad)
     _run("patchify", img.numel() * (img.element_size() + 2.0), "byte",
-         lambda: _lib.load().xvit_patchify(_ptr(img), _dt(img), _ptr(out), B, M, D, H, W, dp, hp, wp, pad, _stream()), "xvit_patchify")
+         lambda: _lib.load().xvit_patchify(_ptr(img), _dt(img), _ptr(out), B, M, D, H, W, dp, hp, wp, *place, _stream()), "xvit_patchify")
     return out
 
 

@@ -139,13 +139,16 @@ int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v,
                        float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * 3-D patchify (model_cross.py:193): img [B, M, 1, D, H, W] (fp32 or bf16, contiguous) ->
- * patches bf16 [M, B, P + pad, pd]; token t = (h*Wn + w)*Dn + d, feature f = (p1*hp + p2)*wp + p3.
- * pad_cls_row = 1 leaves an all-zero row 0 in front of every sample's P patch rows, so the patch
- * matrix lines up row-for-row with the [M*B, N = P+1, d] token tensor (the CLS row, :195-196).
+ * 3-D patchify (model_cross.py:193, modelv3.py:129): img [B, M, 1, D, H, W] (fp32 or bf16, contiguous) ->
+ * rows of a bf16 patch matrix [*, pd]; token t = (h*Wn + w)*Dn + d, feature f = (p1*hp + p2)*wp + p3.
+ * Patch (b, m, t) goes to row  b*stride_b + m*stride_m + t + row_off,  so the same kernel lays the rows out
+ *   per modality with a CLS slot  (ModelCross: stride_b = P+1, stride_m = B*(P+1), row_off = 1) or
+ *   concatenated per sample       (ModelVIT:   stride_b = M*P+1, stride_m = P,     row_off = 1).
+ * zero_rows rows (0, zero_row_stride, 2*zero_row_stride, ...) are zero-filled: the CLS slots, so the patch
+ * matrix lines up row-for-row with the token tensor (model_cross.py:195-196).
  * ---------------------------------------------------------------------------------------- */
 int xvit_patchify(const void* img, int img_dtype, void* patches_bf16, int B, int M, int D, int H, int W, int dp, int hp, int wp,
-                  int pad_cls_row, xvit_stream_t stream);
+                  int64_t stride_b, int64_t stride_m, int row_off, int zero_rows, int64_t zero_row_stride, xvit_stream_t stream);
 /* x[m, b, 0, :] = cls + pos[0]  (model_cross.py:195-197, the CLS row); x fp32 [M*B, N, d] */
 int xvit_cls_row_fwd(const float* cls, const float* pos, float* x, int MB, int N, int d, xvit_stream_t stream);
 /* dpos[n,:] += sum_{mb} dx[mb,n,:];  dcls += sum_{mb} dx[mb,0,:] */

@@ -11,6 +11,10 @@ How the reference is executed:
     that provide only a base class (``LightningModule := nn.Module`` + no-op ``log``), an
     attribute-dict config type and six unused metric names.  No arithmetic on the hot
     path comes from them: every line that computes is the reference's, run on CPU torch.
+  * ``modelv3.py`` imports torchvision (absent): its five classes on the path (PreNorm, FeedForward, Attention,
+    Transformer, ModelVIT) are exec'd from the AST with ``StochasticDepth`` bound to an identity module — the
+    reference constructs every instance with rate 0 (modelv3.py:73), for which torchvision's own forward
+    returns its input unchanged.
   * ``model.py`` cannot be imported at all (module-level dataset construction), so its
     four encoder classes are taken as AST ``ClassDef`` nodes and exec'd in a namespace
     that provides torch/nn/math/copy — again the reference's own statements.
@@ -76,6 +80,22 @@ def import_reference():
     for node in tree.body:
         if isinstance(node, ast.ClassDef) and node.name in {"Mlp", "MultiHeadAttention", "Block", "Encoder"}:
             exec(compile(ast.Module([node], []), "model.py", "exec"), ns)
+    from einops import rearrange, repeat
+
+    class StochasticDepth(nn.Module):          # p = 0 everywhere in the reference -> identity
+        def __init__(self, p, mode):
+            super().__init__()
+            assert p == 0.0
+        def forward(self, x):
+            return x
+
+    ns3 = dict(torch=torch, nn=nn, F=torch.nn.functional, L=L, rearrange=rearrange, repeat=repeat, StochasticDepth=StochasticDepth)
+    with open(os.path.join(REF, "modelv3.py")) as fh:
+        tree3 = ast.parse(fh.read())
+    for node in tree3.body:
+        if isinstance(node, ast.ClassDef) and node.name in {"PreNorm", "FeedForward", "Attention", "Transformer", "ModelVIT"}:
+            exec(compile(ast.Module([node], []), "modelv3.py", "exec"), ns3)
+    ns["ModelVIT"] = ns3["ModelVIT"]
     return model_cross, ns, ConfigDict
 
 
@@ -258,6 +278,33 @@ def golden_encoder(ns, ConfigDict, chk: Checker):
     return out
 
 
+def golden_model_vit(ns, ConfigDict, chk: Checker):
+    """modelv3.ModelVIT at a tail-heavy small shape (3 modalities -> N = 3*16 + 1 = 49... with config "small": 3*16+1)."""
+    out = {}
+    cfg = R.make_config("small", num_layers=2)
+    sd = R.make_vit_state_dict(cfg, seed=11)
+    img, labels = R.make_inputs(cfg, 3, seed=4)
+    model = ns["ModelVIT"](to_ref_config(cfg, ConfigDict))
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model.train()
+    logits, loss = model(img, labels)
+    loss.backward()
+    cap = {}
+    my_logits, my_loss = R.model_vit_forward(sd, img, labels, cfg, capture=cap)
+    chk.close("ModelVIT/logits", my_logits, logits.detach(), 2e-5)
+    chk.close("ModelVIT/loss", my_loss, loss.detach(), 2e-6)
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()}
+    R.model_vit_forward(leaf, img, labels, cfg)[1].backward()
+    ref_grads = {k: p.grad.detach() for k, p in model.named_parameters()}
+    for k in ref_grads:
+        chk.close(f"ModelVIT/grad/{k}", leaf[k].grad, ref_grads[k], 5e-4)
+    out.update(logits=logits.detach().numpy(), loss=np.float64(loss.item()), labels=labels.numpy(), img_sha256=R.tensor_sha256(img),
+               sd_sha256=R.tensor_sha256(torch.cat([v.reshape(-1) for _, v in sorted(sd.items())])))
+    out.update(grad_summary(ref_grads))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true", help="verify only; do not write fixtures")
@@ -270,6 +317,7 @@ def main():
     files = {
         "blocks.npz": golden_blocks(Mref, ConfigDict, chk),
         "encoder.npz": golden_encoder(ns, ConfigDict, chk),
+        "model_vit_small.npz": golden_model_vit(ns, ConfigDict, chk),
         "model_cross_tiny.npz": golden_model_cross(Mref, ConfigDict, "tiny", 4, chk, full=True),
         "model_cross_small.npz": golden_model_cross(Mref, ConfigDict, "small", 2, chk, full=True),
     }

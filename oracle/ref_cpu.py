@@ -379,6 +379,49 @@ def model_cross_loss_and_grads(sd, img, labels, cfg):
 
 
 # --------------------------------------------------------------------------------------
+# modelv3.ModelVIT (modelv3.py:90-147): all modalities' patch tokens in ONE sequence, same blocks
+# --------------------------------------------------------------------------------------
+
+
+def make_vit_state_dict(cfg, seed: int = 0) -> dict:
+    g = derived(cfg)
+    gen = torch.Generator().manual_seed(seed)
+    sd = {}
+    sd["pos_embedding"] = 0.02 * torch.randn(1, g.M * g.P + 1, g.d, generator=gen)
+    sd["cls_token"] = 0.02 * torch.randn(1, 1, g.d, generator=gen)
+    _linear(sd, gen, "patch_to_embedding", g.d, g.pd)
+    for l in range(cfg.num_layers):
+        p = f"transformer.layers.{l}"
+        _norm(sd, gen, p + ".0.norm", g.d)
+        _linear(sd, gen, p + ".0.fn.to_qkv", 3 * g.d, g.d, bias=False)
+        _linear(sd, gen, p + ".0.fn.to_out.0", g.d, g.d)
+        _norm(sd, gen, p + ".2.norm", g.d)
+        _linear(sd, gen, p + ".2.fn.net.0", g.f, g.d)
+        _linear(sd, gen, p + ".2.fn.net.3", g.d, g.f)
+    _norm(sd, gen, "mlp_head.0", g.d)
+    _linear(sd, gen, "mlp_head.1", g.f, g.d)
+    _linear(sd, gen, "mlp_head.4", cfg.num_classes, g.f)
+    return sd
+
+
+def model_vit_forward(sd, img, labels, cfg, capture: dict | None = None):
+    """modelv3.py:123-147 -> (logits, loss)."""
+    H = cfg.num_heads
+    toks = [linear(patchify(img[:, m, 0], cfg.patch_size), sd["patch_to_embedding.weight"], sd["patch_to_embedding.bias"]) for m in range(img.shape[1])]
+    x = torch.cat([sd["cls_token"].expand(img.shape[0], -1, -1)] + toks, dim=1) + sd["pos_embedding"]
+    for l in range(cfg.num_layers):
+        p = f"transformer.layers.{l}"
+        x = self_attention(sd, p + ".0.fn", layer_norm(x, sd[p + ".0.norm.weight"], sd[p + ".0.norm.bias"]), H) + x
+        x = feed_forward(sd, p + ".2.fn", layer_norm(x, sd[p + ".2.norm.weight"], sd[p + ".2.norm.bias"])) + x
+        if capture is not None:
+            capture[f"layer{l}"] = x
+    c = layer_norm(x[:, 0], sd["mlp_head.0.weight"], sd["mlp_head.0.bias"])
+    h = gelu(linear(c, sd["mlp_head.1.weight"], sd["mlp_head.1.bias"]))
+    logits = linear(h, sd["mlp_head.4.weight"], sd["mlp_head.4.bias"], w_exact=True)
+    return logits, cross_entropy(logits, labels)
+
+
+# --------------------------------------------------------------------------------------
 # model.py twin (model.py:107-214): separate biased q/k/v/out, /sqrt(dh), LN eps 1e-6
 # --------------------------------------------------------------------------------------
 

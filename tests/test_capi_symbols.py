@@ -38,6 +38,8 @@ def test_modules_have_reference_state_dict_keys():
         assert set(model.state_dict()) == set(R.make_state_dict(cfg)), name
         res = model.load_state_dict(R.make_state_dict(cfg), strict=True)
         assert not res.missing_keys and not res.unexpected_keys
+    cfgv = R.make_config("small", num_layers=2)
+    assert set(xvit.ModelVIT(cfgv).state_dict()) == set(R.make_vit_state_dict(cfgv))
     from types import SimpleNamespace
     enc = xvit.Encoder(SimpleNamespace(hidden_size=256, transformer=dict(num_heads=4, mlp_dim=512, dropout_rate=0.0, attention_dropout_rate=0.0, num_layers=2)))
     assert set(enc.state_dict()) == set(R.make_encoder_state_dict(256, 512, 2))

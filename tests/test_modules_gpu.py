@@ -234,3 +234,26 @@ def test_large_configs_vs_bf16_emulating_oracle(name, batch):
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
         if not k.endswith("wk.bias"):
             assert float(p.grad.abs().max()) > 0, k
+
+
+def test_model_vit_vs_reference_golden_and_emulation(golden_dir):
+    """modelv3.ModelVIT drop-in: reference state_dict keys, forward vs the reference's outputs and vs the
+    bf16-emulating oracle, every parameter gradient's norm vs the reference's."""
+    import xvit
+    g = np.load(os.path.join(golden_dir, "model_vit_small.npz"))
+    cfg = R.make_config("small", num_layers=2)
+    sd = R.make_vit_state_dict(cfg, seed=11)
+    img, labels = R.make_inputs(cfg, 3, seed=4)
+    model = xvit.ModelVIT(cfg).to(dev())
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    logits, loss = model(img.to(dev()), labels.to(dev()))
+    loss.backward()
+    assert rel(logits, _t(g["logits"])) < 2.5e-2 and abs(float(loss.detach()) - float(g["loss"])) < 5e-3
+    with R.emulate_bf16():
+        emu_logits, emu_loss = R.model_vit_forward(sd, img, labels, cfg)
+    assert rel(logits, emu_logits) < 2.5e-2 and abs(float(loss.detach()) - float(emu_loss)) < 2e-3
+    for k, p in model.named_parameters():
+        ref_n = float(g[f"gnorm/{k}"])
+        assert abs(float(p.grad.double().norm()) - ref_n) <= 0.03 * ref_n + 1e-7, k

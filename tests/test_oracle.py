@@ -106,3 +106,14 @@ def test_flop_model_matches_baseline():
 def test_base_logits_golden_present(golden_dir):
     g = np.load(os.path.join(golden_dir, "model_cross_base.npz"))
     assert g["logits"].shape == (2, 2) and np.isfinite(g["logits"]).all()
+
+
+def test_model_vit_matches_reference(golden_dir):
+    """modelv3.ModelVIT (the reference's concatenated-token comparison arm)."""
+    g = np.load(os.path.join(golden_dir, "model_vit_small.npz"))
+    cfg = R.make_config("small", num_layers=2)
+    sd = R.make_vit_state_dict(cfg, seed=11)
+    img, labels = R.make_inputs(cfg, 3, seed=4)
+    assert str(g["img_sha256"]) == R.tensor_sha256(img) and str(g["sd_sha256"]) == _sd_hash(sd)
+    logits, loss = R.model_vit_forward(sd, img, labels, cfg)
+    assert rel(logits, g["logits"]) < TOL and abs(float(loss) - float(g["loss"])) < 1e-5
