@@ -310,3 +310,63 @@ extern "C" int xvit_mean_ce(const float* logits_m, const int64_t* labels, float 
   hipLaunchKernelGGL(mean_ce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits_m, labels, label_smoothing, logits, loss, dlogits_m, M, B, C);
   return check_launch("xvit_mean_ce");
 }
+
+// ------------------------------------------------------------------------------------------
+// Fused multi-tensor Adam (reference: torch.optim.Adam(lr, weight_decay) at model_cross.py:277 — L2 decay added
+// to the gradient, bias-corrected moments, eps outside the square root).  One launch updates every tensor of a
+// parameter group: p, m, v in fp32 and, when given, the bf16 operand copy of p (so no separate cast pass).
+// ------------------------------------------------------------------------------------------
+namespace xvit {
+struct AdamTensor { float* p; const float* g; float* m; float* v; bf16* shadow; int64_t n; };
+constexpr int ADAM_CHUNK = 16384;   // elements per block
+
+__global__ __launch_bounds__(256) void adam_kernel(const AdamTensor* __restrict__ table, const int2* __restrict__ chunks, float lr_over_bc1,
+                                                   float beta1, float beta2, float eps, float wd, float inv_sqrt_bc2, float grad_scale) {
+  const int2 ch = chunks[blockIdx.x];
+  const AdamTensor t = table[ch.x];
+  const int64_t begin = (int64_t)ch.y * ADAM_CHUNK;
+  const int64_t end = begin + ADAM_CHUNK < t.n ? begin + ADAM_CHUNK : t.n;
+  const bool vec = ((reinterpret_cast<uintptr_t>(t.p) | reinterpret_cast<uintptr_t>(t.g) | reinterpret_cast<uintptr_t>(t.m) |
+                     reinterpret_cast<uintptr_t>(t.v)) & 15) == 0 && (!t.shadow || (reinterpret_cast<uintptr_t>(t.shadow) & 7) == 0);
+  auto upd = [&](float& p, float g, float& m, float& v) {
+    g = g * grad_scale + wd * p;
+    m = beta1 * m + (1.0f - beta1) * g;
+    v = beta2 * v + (1.0f - beta2) * g * g;
+    p -= lr_over_bc1 * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
+  };
+  if (vec) {
+    for (int64_t i = begin + threadIdx.x * 4; i + 3 < end; i += 256 * 4) {
+      f32x4 p = *(f32x4*)(t.p + i), m = *(f32x4*)(t.m + i), v = *(f32x4*)(t.v + i);
+      const f32x4 g = *(const f32x4*)(t.g + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // vector elements cannot bind to references: go through scalars
+        float pe = p[e], me = m[e], ve = v[e];
+        upd(pe, g[e], me, ve);
+        p[e] = pe; m[e] = me; v[e] = ve;
+      }
+      *(f32x4*)(t.p + i) = p; *(f32x4*)(t.m + i) = m; *(f32x4*)(t.v + i) = v;
+      if (t.shadow) *(bf16x4*)(t.shadow + i) = bf16x4{f2bf(p[0]), f2bf(p[1]), f2bf(p[2]), f2bf(p[3])};
+    }
+    const int64_t tail = begin + ((end - begin) & ~(int64_t)3);
+    for (int64_t i = tail + threadIdx.x; i < end; i += 256) {
+      upd(t.p[i], t.g[i], t.m[i], t.v[i]);
+      if (t.shadow) t.shadow[i] = f2bf(t.p[i]);
+    }
+  } else {
+    for (int64_t i = begin + threadIdx.x; i < end; i += 256) {
+      upd(t.p[i], t.g[i], t.m[i], t.v[i]);
+      if (t.shadow) t.shadow[i] = f2bf(t.p[i]);
+    }
+  }
+}
+}  // namespace xvit
+
+extern "C" int xvit_adam_step(const void* table_dev, const void* chunks_dev, int n_chunks, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, int step, float grad_scale, xvit_stream_t stream) {
+  XVIT_REQUIRE(table_dev && chunks_dev && n_chunks > 0 && step >= 1, "xvit_adam_step: bad arguments");
+  XVIT_REQUIRE(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "xvit_adam_step: bad hyper-parameters");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(xvit::adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const xvit::AdamTensor*)table_dev, (const int2*)chunks_dev,
+                     (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale);
+  return xvit::check_launch("xvit_adam_step");
+}

@@ -163,6 +163,18 @@ int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, i
 int xvit_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, xvit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused multi-tensor Adam step with torch.optim.Adam semantics (model_cross.py:276-278: L2 weight decay added to
+ * the gradient, bias correction with `step`, eps outside the square root).  table_dev: device array of
+ *   struct { float* p; const float* g; float* m; float* v; void* shadow_bf16 (or NULL); int64_t n; }
+ * chunks_dev: device array of int32 pairs (tensor index, chunk index), one block per 16384-element chunk.
+ * When shadow_bf16 is given it receives bf16(p) — the GEMM operand copy, so no cast pass follows the step.
+ * grad_scale multiplies every gradient first (1 for plain training).
+ * ---------------------------------------------------------------------------------------- */
+#define XVIT_ADAM_CHUNK 16384
+int xvit_adam_step(const void* table_dev, const void* chunks_dev, int n_chunks, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, float grad_scale, xvit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Head tail (model_cross.py:205-211): logits = mean_m logits_m;  loss = CE(logits, labels,
  * label_smoothing), mean over the batch.  Also writes dlogits_m[M,B,C] = d loss / d logits_m.
  * ---------------------------------------------------------------------------------------- */
