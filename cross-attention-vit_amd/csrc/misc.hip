@@ -370,3 +370,38 @@ extern "C" int xvit_adam_step(const void* table_dev, const void* chunks_dev, int
                      (float)(lr / bc1), beta1, beta2, eps, weight_decay, (float)(1.0 / sqrt(bc2)), grad_scale);
   return xvit::check_launch("xvit_adam_step");
 }
+
+// ------------------------------------------------------------------------------------------
+// Input stage (reference dataset_ucsf.py:84-88,152-158): MONAI ResizeWithPadOrCropd(spatial_size, constant_values=-1)
+// = symmetric pad (before = deficit/2, after = the rest) then centre crop (start = size/2 - target/2), then .float().
+// Here: int16 NIfTI payload [nvol, Ds, Hs, Ws] on the device -> bf16 [nvol, D, H, W], one pass, no fp32 volume.
+// ------------------------------------------------------------------------------------------
+namespace xvit {
+__global__ void resize_pad_crop_i16_kernel(const int16_t* __restrict__ src, bf16* __restrict__ dst, int Ds, int Hs, int Ws, int D, int H, int W,
+                                           int od, int oh, int ow, float pad_value, int64_t total) {
+  // (od, oh, ow): source index = destination index + offset; negative offsets are padding
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    int64_t r = i / W;
+    const int h = (int)(r % H); r /= H;
+    const int d = (int)(r % D);
+    const int64_t vol = r / D;
+    const int sd = d + od, sh = h + oh, sw = w + ow;
+    const bool in = sd >= 0 && sd < Ds && sh >= 0 && sh < Hs && sw >= 0 && sw < Ws;
+    dst[i] = f2bf(in ? (float)src[((vol * Ds + sd) * Hs + sh) * (int64_t)Ws + sw] : pad_value);
+  }
+}
+}  // namespace xvit
+
+extern "C" int xvit_resize_pad_crop_i16(const void* src_i16, void* dst_bf16, int nvol, int Ds, int Hs, int Ws, int D, int H, int W,
+                                        float pad_value, xvit_stream_t stream) {
+  XVIT_REQUIRE(src_i16 && dst_bf16 && nvol > 0 && Ds > 0 && Hs > 0 && Ws > 0 && D > 0 && H > 0 && W > 0, "xvit_resize_pad_crop_i16: bad arguments");
+  // per dimension: size < target -> pad, before = (target - size) / 2; size > target -> crop, start = size / 2 - target / 2
+  auto offset = [](int size, int target) { return size >= target ? size / 2 - target / 2 : -((target - size) / 2); };
+  const int64_t total = (int64_t)nvol * D * H * W;
+  int64_t g = (total + 255) / 256;
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(xvit::resize_pad_crop_i16_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, (const int16_t*)src_i16, (xvit::bf16*)dst_bf16,
+                     Ds, Hs, Ws, D, H, W, offset(Ds, D), offset(Hs, H), offset(Ws, W), pad_value, total);
+  return xvit::check_launch("xvit_resize_pad_crop_i16");
+}

@@ -288,3 +288,16 @@ def mean_ce(logits_m, labels, smoothing):
     dl = torch.empty_like(logits_m)
     _lib.check(_lib.load().xvit_mean_ce(_ptr(logits_m), _ptr(labels), smoothing, _ptr(logits), _ptr(loss), _ptr(dl), M, B, Cn, _stream()), "xvit_mean_ce")
     return logits, loss, dl
+
+
+def resize_pad_crop_i16(vol, img_size, pad_value=-1.0):
+    """int16 [B, M, Ds, Hs, Ws] (NIfTI voxels, on the GPU) -> bf16 [B, M, 1, D, H, W]: the reference's
+    ResizeWithPadOrCropd(img_size, constant_values=-1) + float cast (dataset_ucsf.py:84-88,152-158) in one pass."""
+    assert vol.dtype == torch.int16 and vol.dim() == 5 and vol.is_contiguous()
+    B, M, Ds, Hs, Ws = vol.shape
+    D, H, W = img_size
+    out = torch.empty(B, M, 1, D, H, W, dtype=torch.bfloat16, device=vol.device)
+    _run("resize_pad_crop_i16", vol.numel() * 2.0 + out.numel() * 2.0, "byte",
+         lambda: _lib.load().xvit_resize_pad_crop_i16(_ptr(vol), _ptr(out), B * M, Ds, Hs, Ws, D, H, W, float(pad_value), _stream()),
+         "xvit_resize_pad_crop_i16")
+    return out

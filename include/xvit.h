@@ -149,6 +149,16 @@ int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v,
  * ---------------------------------------------------------------------------------------- */
 int xvit_patchify(const void* img, int img_dtype, void* patches_bf16, int B, int M, int D, int H, int W, int dp, int hp, int wp,
                   int64_t stride_b, int64_t stride_m, int row_off, int zero_rows, int64_t zero_row_stride, xvit_stream_t stream);
+/* ------------------------------------------------------------------------------------------
+ * Input stage (dataset_ucsf.py:84-88, 152-158): MONAI `ResizeWithPadOrCropd(spatial_size, constant_values=pad_value)`
+ * followed by `.to(torch.float)`, on the raw int16 NIfTI voxels already on the device:
+ * src int16 [nvol, Ds, Hs, Ws] -> dst bf16 [nvol, D, H, W].  Per dimension: symmetric pad with before = deficit/2
+ * when the source is smaller, centre crop with start = size/2 - target/2 when it is larger (MONAI SpatialPad
+ * "symmetric" + CenterSpatialCrop).  MONAI is not installed here: PARITY UNPINNED (restated from its documented rule).
+ * ---------------------------------------------------------------------------------------- */
+int xvit_resize_pad_crop_i16(const void* src_i16, void* dst_bf16, int nvol, int Ds, int Hs, int Ws, int D, int H, int W,
+                             float pad_value, xvit_stream_t stream);
+
 /* x[m, b, 0, :] = cls + pos[0]  (model_cross.py:195-197, the CLS row); x fp32 [M*B, N, d] */
 int xvit_cls_row_fwd(const float* cls, const float* pos, float* x, int MB, int N, int d, xvit_stream_t stream);
 /* dpos[n,:] += sum_{mb} dx[mb,n,:];  dcls += sum_{mb} dx[mb,0,:] */

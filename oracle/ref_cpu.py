@@ -379,6 +379,31 @@ def model_cross_loss_and_grads(sd, img, labels, cfg):
 
 
 # --------------------------------------------------------------------------------------
+# input stage: MONAI ResizeWithPadOrCropd(spatial_size, constant_values) + float cast
+# (dataset_ucsf.py:84-88,152-158).  PARITY UNPINNED: MONAI is neither installed nor version-pinned by the
+# reference (requirements.txt:4); this restates its documented rule — SpatialPad(method="symmetric"): pad
+# (deficit // 2) before and the rest after; CenterSpatialCrop: start = size // 2 - roi // 2.
+# --------------------------------------------------------------------------------------
+
+
+def resize_with_pad_or_crop(vol: torch.Tensor, spatial_size, constant_value=-1.0) -> torch.Tensor:
+    """vol [..., Ds, Hs, Ws] (any dtype) -> float32 [..., D, H, W]."""
+    out = vol.to(torch.float32)
+    for ax, target in zip((-3, -2, -1), spatial_size):
+        size = out.shape[ax]
+        if size < target:
+            before = (target - size) // 2
+            pad = [0, 0] * 3
+            pad[2 * (-1 - ax)] = before
+            pad[2 * (-1 - ax) + 1] = target - size - before
+            out = torch.nn.functional.pad(out, pad, value=float(constant_value))
+        elif size > target:
+            start = size // 2 - target // 2
+            out = out.narrow(ax, start, target)
+    return out.contiguous()
+
+
+# --------------------------------------------------------------------------------------
 # modelv3.ModelVIT (modelv3.py:90-147): all modalities' patch tokens in ONE sequence, same blocks
 # --------------------------------------------------------------------------------------
 

@@ -172,3 +172,15 @@ def test_colsum_cast_embed_small_linear_ce_dropout():
     assert torch.equal(y1, y2) and not torch.equal(y1, y3)
     keep = float((y1 != 0).float().mean())
     assert abs(keep - 0.75) < 5e-3 and abs(float(y1.max()) - 1 / 0.75) < 1e-6
+
+
+@pytest.mark.parametrize("src,dst", [((240, 240, 155), (128, 128, 128)), ((20, 31, 17), (32, 32, 16)), ((9, 8, 8), (8, 8, 12))])
+def test_input_stage_resize_pad_crop_int16(src, dst):
+    """int16 volumes -> bf16 model input, against the oracle's restatement of the MONAI rule (bit-exact up to the one
+    bf16 rounding of integer intensities)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    vol = torch.randint(-50, 3000, (2, 2, *src), generator=g, dtype=torch.int16)
+    out = ops.resize_pad_crop_i16(vol.to(dev()), dst, -1.0)
+    ref = R.resize_with_pad_or_crop(vol, dst, -1.0).to(torch.bfloat16).reshape(2, 2, 1, *dst)
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref)

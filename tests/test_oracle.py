@@ -117,3 +117,17 @@ def test_model_vit_matches_reference(golden_dir):
     assert str(g["img_sha256"]) == R.tensor_sha256(img) and str(g["sd_sha256"]) == _sd_hash(sd)
     logits, loss = R.model_vit_forward(sd, img, labels, cfg)
     assert rel(logits, g["logits"]) < TOL and abs(float(loss) - float(g["loss"])) < 1e-5
+
+
+def test_resize_with_pad_or_crop_rule():
+    """Input-stage restatement (parity unpinned: MONAI absent).  Hand-checked cases of the documented rule."""
+    v = torch.arange(5 * 4 * 7, dtype=torch.int16).reshape(5, 4, 7)
+    out = R.resize_with_pad_or_crop(v, (3, 6, 7), -1)          # crop D 5->3 (start 5//2 - 3//2 = 1), pad H 4->6 (1 before, 1 after)
+    assert out.shape == (3, 6, 7)
+    assert torch.equal(out[:, 1:5, :], v[1:4].float()) and bool((out[:, 0] == -1).all()) and bool((out[:, 5] == -1).all())
+    out = R.resize_with_pad_or_crop(v, (8, 4, 4), -1)          # pad D 5->8 (1 before, 2 after), crop W 7->4 (start 3 - 2 = 1)
+    assert torch.equal(out[1:6], v[:, :, 1:5].float()) and bool((out[0] == -1).all()) and bool((out[6:] == -1).all())
+    # the UCSF-PDGM shape of the reference's sample data: 240x240x155 -> 128^3 is a pure centre crop
+    big = torch.zeros(240, 240, 155, dtype=torch.int16); big[56, 56, 13] = 7; big[183, 183, 140] = 9
+    out = R.resize_with_pad_or_crop(big, (128, 128, 128), -1)
+    assert out[0, 0, 0] == 7 and out[127, 127, 127] == 9
