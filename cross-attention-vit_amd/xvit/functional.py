@@ -9,6 +9,7 @@ are re-cast whenever a parameter's version changes (i.e. after every optimizer s
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import torch
@@ -175,12 +176,43 @@ def _wgrad_split(m, n, k):
     return max(1, min(512 // max(tiles, 1), ((k + 63) // 64) // 8, 32))
 
 
+_WGRAD_STREAMS = {}
+
+
+def _wgrad_stream(cur):
+    """Companion stream of `cur` for weight-gradient GEMMs (opt-in with XVIT_WGRAD_STREAM=1: measured neutral, 18.14 vs 18.36 ms, once the modality streams overlap)."""
+    if os.environ.get("XVIT_WGRAD_STREAM", "0") != "1" or ops.PROFILE is not None:
+        return None
+    key = (cur.device, cur.cuda_stream)
+    if key not in _WGRAD_STREAMS:
+        _WGRAD_STREAMS[key] = torch.cuda.Stream(device=cur.device)
+    return _WGRAD_STREAMS[key]
+
+
 def _wgrad(dy_b, x_b):
-    """dW[out, in] = dy^T x over all rows (tokens); fp32."""
+    """dW[out, in] = dy^T x over all rows (tokens); fp32.  Weight gradients are off the critical path of a block's
+    backward (nothing downstream reads them), so large ones are issued on a companion stream and overlap the
+    HBM-bound kernels of the dgrad chain; `_join_wgrads()` re-joins before the Function returns."""
     out_f, in_f, k = dy_b.shape[1], x_b.shape[1], dy_b.shape[0]
-    dW = torch.empty(out_f, in_f, dtype=torch.float32, device=dy_b.device)
-    ops.gemm(ops.TN, dy_b, x_b, dW, split_k=_wgrad_split(out_f, in_f, k))
+    cur = torch.cuda.current_stream(dy_b.device)
+    ws = _wgrad_stream(cur) if k >= 1024 else None
+    if ws is None:
+        dW = torch.empty(out_f, in_f, dtype=torch.float32, device=dy_b.device)
+        ops.gemm(ops.TN, dy_b, x_b, dW, split_k=_wgrad_split(out_f, in_f, k))
+        return dW
+    ws.wait_stream(cur)                       # operands are produced on `cur`
+    with torch.cuda.stream(ws):
+        dW = torch.empty(out_f, in_f, dtype=torch.float32, device=dy_b.device)
+        ops.gemm(ops.TN, dy_b, x_b, dW, split_k=_wgrad_split(out_f, in_f, k))
     return dW
+
+
+def _join_wgrads(device):
+    """Make the current stream wait for its companion wgrad stream (operand tensors may be freed afterwards)."""
+    cur = torch.cuda.current_stream(device)
+    ws = _WGRAD_STREAMS.get((cur.device, cur.cuda_stream))
+    if ws is not None:
+        cur.wait_stream(ws)
 
 
 def _skinny_split(m, n, k):
@@ -277,6 +309,7 @@ def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w
     if has_bqkv:
         g["bqkv"] = ops.colsum(dqkv)
     dx, _ = ops.layernorm_bwd(dh1, x, mu1, rs1, ln1w, g["ln1w"], g["ln1b"], dres=dx1)
+    _join_wgrads(x.device)
     return dx, g
 
 
@@ -389,6 +422,7 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
     g["wq"] = _wgrad(dqb, hn0)
     g["bq"] = ops.colsum(dq)
     dcat, _ = ops.layernorm_bwd(dhn, xj, mu, rs, ln1w, g["ln1w"], g["ln1b"], x_alt=xi, seq_len=N)
+    _join_wgrads(xi.device)
     return dcat, dy, g
 
 
@@ -476,6 +510,7 @@ class PatchEmbedFn(Function):
         dcls = torch.zeros(d, dtype=torch.float32, device=dx.device)
         ops.embed_bwd(dx2, dpos, dcls, M * Bn, N, d)
         db = ops.colsum(dpos[1:])            # bias reaches the P patch rows of every sample
+        _join_wgrads(dx.device)
         return None, dW, db, dcls.reshape(1, 1, d), dpos.reshape(1, N, d), None, None, None
 
 
@@ -519,6 +554,7 @@ class HeadFn(Function):
         db0 = ops.colsum(dz)
         dg, dbeta = _zeros(d, dl), _zeros(d, dl)
         dxc, _ = ops.layernorm_bwd(dh, x2, mu, rs, lnw, dg, dbeta)
+        _join_wgrads(dl.device)
         dx = torch.zeros(B, N, d, dtype=torch.float32, device=dl.device)
         dx[:, 0] = dxc
         return dx, dg, dbeta, dW0, db0, dW3, db3, None, None
@@ -598,7 +634,9 @@ class LinearFn(Function):
         if p > 0.0:
             dyb = ops.dropout(dyb, p, seed)
         dx = _dgrad(dyb, w_s).reshape(shape)
-        return dx.to(xdtype), _wgrad(dyb, x2), (ops.colsum(dyb) if has_b else None), None, None
+        dW = _wgrad(dyb, x2)
+        _join_wgrads(dyb.device)
+        return dx.to(xdtype), dW, (ops.colsum(dyb) if has_b else None), None, None
 
 
 class FeedForwardFn(Function):
@@ -625,7 +663,9 @@ class FeedForwardFn(Function):
             dyb = ops.dropout(dyb, p, seeds[1])
         dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, dropout=_dp(p, seeds[0]))
         dx = _dgrad(dz, w1_s).reshape(shape)
-        return dx.to(xdtype), _wgrad(dz, x2), ops.colsum(dz), _wgrad(dyb, a), ops.colsum(dyb), None
+        dW1, dW2 = _wgrad(dz, x2), _wgrad(dyb, a)
+        _join_wgrads(dyb.device)
+        return dx.to(xdtype), dW1, ops.colsum(dz), dW2, ops.colsum(dyb), None
 
 
 class AttentionCoreFn(Function):
