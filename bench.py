@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape GEMM table on stderr (diagnostic)")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (xvit.graph.GraphedStep); "
+                    "pays off when the step is host-bound, i.e. at small per-GPU batch")
     ap.add_argument("--single-stream", action="store_true", help="run the modality branches on one stream (used for the rocprof "
                     "summary under profiles/, so per-kernel durations are not stretched by a concurrently running kernel)")
     args = ap.parse_args()
@@ -167,6 +169,16 @@ def main():
             reducer.finish()
         return loss
 
+    if args.graph:
+        if use_dist:
+            raise SystemExit("--graph is a single-GPU mode")
+        from xvit.graph import GraphedStep
+        graphed = GraphedStep(model, img, labels)
+        eager_step = step
+
+        def step():                                   # noqa: F811
+            return graphed()[1]
+
     def fence():
         torch.cuda.synchronize(dev)
         if use_dist:
@@ -202,13 +214,15 @@ def main():
         "config": {"workload": "configs[1]: ModelCross d=768 H=12 mlp=3072 2x2 blocks, 2 modalities, 128^3 volume, 16^3 patches (N=513), dropout 0",
                    "per_gpu_batch": B, "global_batch": world * B, "seq_len": P + 1, "parallelism": f"dp{world}",
                    "step": "zero-grad + weight bf16 cast + fwd + loss + bwd" + (" + bucketed grad all-reduce (RCCL, side stream)" if world > 1 else ""),
-                   "optimizer_step": "excluded"},
+                   "optimizer_step": "excluded", "launch": "one HIP graph replay per step" if args.graph else "eager (one launch per kernel)"},
         "model_tflops_per_gpu": round(both_f * B / (dt / args.steps) / 1e12, 1),
         "mfma_frac_of_peak_step": round(both_f * B / (dt / args.steps) / 1e12 / MFMA_PEAK_TF, 4),
         "loss": round(loss_val, 5),
     }
 
     # ---- per-kernel pricing with HIP events on the launch stream (rank 0) --------------------
+    if args.graph:
+        step = eager_step                             # per-kernel pricing needs individual launches
     if rank == 0 and args.profile_steps > 0:
         # kernels are priced one at a time: the two modality streams are merged for these extra steps, otherwise
         # concurrently running kernels stretch each other's event brackets (the timed region above keeps them)

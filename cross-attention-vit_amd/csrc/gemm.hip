@@ -558,7 +558,14 @@ using namespace xvit;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-static bool use_big_tile(const xvit_gemm_args* a) { return a->M >= 256 && a->N >= 256; }
+// 256x256 tiles (one block per CU, 128 FLOP per staged byte) unless their grid would occupy at most half of the
+// 256 CUs: then the 128x128 kernel (4x the blocks, two per CU) finishes sooner despite its lower intensity
+// (e.g. the reference's batch 8: M = 4104 rows -> 17 x 3 big tiles for a d-wide GEMM).
+static bool use_big_tile(const xvit_gemm_args* a) {
+  if (a->M < 256 || a->N < 256) return false;
+  const int64_t big_blocks = (int64_t)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->batch * (a->split_k > 0 ? a->split_k : 1);
+  return big_blocks > 128;
+}
 
 extern "C" int64_t xvit_gemm_workspace_bytes(const xvit_gemm_args* a) {
   if (!a || a->split_k <= 1) return 0;

@@ -85,6 +85,11 @@ __global__ void cast_kernel(const float* __restrict__ src, bf16* __restrict__ ds
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nv << 3) + threadIdx.x] = f2bf(src[(nv << 3) + threadIdx.x]);
 }
 
+__global__ void zero_f32_kernel(float* __restrict__ p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 // column sums: block = 64 column-quads (256 columns) x 4 row lanes over a contiguous slab of rows;
 // 4 independent 16-B loads in flight per thread; one atomic per column per block
 template <typename T>
@@ -268,10 +273,8 @@ extern "C" int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, 
   XVIT_REQUIRE(x && out && rows > 0 && n > 0, "xvit_colsum: bad arguments");
   XVIT_REQUIRE(n % 4 == 0 && ldx % 4 == 0, "xvit_colsum: n and ldx must be multiples of 4");
   hipStream_t s = (hipStream_t)stream;
-  if (!accumulate) {
-    const hipError_t e = hipMemsetAsync(out, 0, (size_t)n * sizeof(float), s);
-    if (e != hipSuccess) { set_error("xvit_colsum: memset failed: %s", hipGetErrorString(e)); return (int)e; }
-  }
+  if (!accumulate)   // a kernel, not hipMemsetAsync: the memset node was observed not to replay from a captured HIP graph
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, n);
   const int gx = (n / 4 + 63) / 64;
   int rpb = 64;                                   // rows per block: >= 64, and at most ~2048 blocks in all
   while ((int64_t)gx * ((rows + rpb - 1) / rpb) > 2048) rpb *= 2;

@@ -171,7 +171,7 @@ def _wgrad_split(m, n, k):
     """Split-K factor for a TN wgrad: enough workgroups to fill 256 CUs, >= 8 K-steps each."""
     if m >= 256 and n >= 256:   # 256x256 tiles, one block per CU
         tiles = ((m + 255) // 256) * ((n + 255) // 256)
-        return max(1, min(256 // max(tiles, 1), ((k + 63) // 64) // 8, 16))
+        return max(1, min(256 // max(tiles, 1), ((k + 63) // 64) // 4, 16))
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
     return max(1, min(512 // max(tiles, 1), ((k + 63) // 64) // 8, 32))
 
@@ -236,7 +236,8 @@ def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None, colsum=None, dropout=None):
     m, n, k = dy_b.shape[0], w_s.shape[1], w_s.shape[0]
     dx = torch.empty(m, n, dtype=torch.bfloat16, device=dy_b.device)
     split = _skinny_split(m, n, k)
-    fused = colsum is not None and (split > 1 or m < 256 or n < 256)
+    big = m >= 256 and n >= 256 and ((m + 255) // 256) * ((n + 255) // 256) * max(split, 1) > 128    # use_big_tile() of gemm.hip
+    fused = colsum is not None and (split > 1 or not big)
     ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=colsum if fused else None, dropout=dropout, split_k=split)
     if colsum is not None and not fused:
         ops.colsum(dx, out=colsum, accumulate=True)

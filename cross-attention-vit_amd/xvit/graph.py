@@ -1,0 +1,73 @@
+"""HIP-graph capture of one training step (zero-grad + weight cast + forward + loss + backward).
+
+At the reference's batch size (8 volume pairs per GPU, main_mist.py:206) the ~480 kernel launches of a step cost more
+host time (8 ms of Python + launch issue) than GPU time (~4 ms): replaying them as ONE graph launch removes the host
+from the loop.  Every libxvit_hip entry point only enqueues on the stream it is given (no allocation, no
+synchronisation), so the whole step is capturable; torch's caching allocator serves the step's tensors from the
+graph's private pool.
+
+    step = GraphedStep(model, img_example, labels_example)   # warm-up + capture
+    logits, loss = step(img, labels)                         # copies into the static inputs, replays; p.grad are filled
+    optimizer.step()                                         # outside the graph
+
+Restrictions: static shapes; dropout must be inactive (masks are seeded on the host per call, a replay would repeat
+them); the modality branches are captured on one stream.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+from . import functional as XF
+
+
+class GraphedStep:
+    def __init__(self, model, img, labels, warmup: int = 3):
+        if not img.is_cuda:
+            raise RuntimeError("GraphedStep needs GPU tensors")
+        for m in model.modules():
+            if isinstance(m, torch.nn.Dropout) and m.p > 0 and model.training:
+                raise RuntimeError("GraphedStep: dropout is active; its host-side seeds cannot be captured (use p = 0 or eval)")
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.img = img.clone()
+        self.labels = labels.clone()
+        self._prev_streams = os.environ.get("XVIT_STREAMS")
+        os.environ["XVIT_STREAMS"] = "0"
+        side = torch.cuda.Stream(device=img.device)
+        side.wait_stream(torch.cuda.current_stream(img.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._eager()
+        torch.cuda.current_stream(img.device).wait_stream(side)
+        torch.cuda.synchronize(img.device)
+        self.graph = torch.cuda.CUDAGraph()
+        for p in self.params:
+            p.grad = None                      # gradients are (re)allocated from the graph's private pool
+        with torch.cuda.graph(self.graph):
+            self.logits, self.loss = self._eager(zero=False)
+        self._restore_env()
+
+    def _restore_env(self):
+        if self._prev_streams is None:
+            os.environ.pop("XVIT_STREAMS", None)
+        else:
+            os.environ["XVIT_STREAMS"] = self._prev_streams
+
+    def _eager(self, zero=True):
+        if zero:
+            for p in self.params:
+                p.grad = None
+        XF.SHADOWS.force = True                # the captured step always re-casts the weights (they change every step)
+        logits, loss = self.model(self.img, self.labels)
+        loss.backward()
+        return logits, loss
+
+    def __call__(self, img=None, labels=None):
+        if img is not None:
+            self.img.copy_(img, non_blocking=True)
+        if labels is not None:
+            self.labels.copy_(labels, non_blocking=True)
+        self.graph.replay()
+        return self.logits, self.loss

@@ -113,7 +113,8 @@ def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NON
             a.workspace, a.workspace_bytes = _ptr(ws), need
     # one family per kernel symbol: gemm_big_kernel<..> (M, N >= 256) vs gemm_kernel<..>; "+splitk" brackets also
     # contain the splitk_epilogue_kernel launch that follows
-    tag = ("gemm_big_" if (a.M >= 256 and a.N >= 256) else "gemm_small_") + ("nt", "nn", "tn")[layout] + ("+splitk" if split_k > 1 else "")
+    big = a.M >= 256 and a.N >= 256 and ((a.M + 255) // 256) * ((a.N + 255) // 256) * a.batch * max(split_k, 1) > 128   # = use_big_tile() in gemm.hip
+    tag = ("gemm_big_" if big else "gemm_small_") + ("nt", "nn", "tn")[layout] + ("+splitk" if split_k > 1 else "")
     if PROFILE is not None and PROFILE_SHAPES:
         epi = ("+b" if bias is not None else "") + ("+gelu" if act == ACT_GELU else "+dgelu" if act == ACT_DGELU else "") + ("+res" if residual is not None else "")
         tag += f"[{a.M}x{a.N}x{a.K}{epi}{'' if a.c_dtype == BF16 else ',f32'}{',s%d' % split_k if split_k > 1 else ''}]"

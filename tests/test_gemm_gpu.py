@@ -82,7 +82,7 @@ def test_epilogue_dgelu():
     assert_close(C, (dy @ w) * _dgelu(z), "dgelu")
 
 
-@pytest.mark.parametrize("M,split", [(1026, 1), (32, 1), (32, 6), (300, 3)])
+@pytest.mark.parametrize("M,split", [(1026, 1), (3000, 1), (32, 1), (32, 6), (300, 3)])
 def test_epilogue_dgelu_colsum_and_split(M, split):
     """GELU' epilogue + column sums of the result (bias gradient), direct and through the split-K
     second pass (small-M GEMMs are split to hide their serial K loop)."""
@@ -91,7 +91,8 @@ def test_epilogue_dgelu_colsum_and_split(M, split):
     dy, w, z = rt(randn(M, K, seed=1)), rt(randn(K, N, seed=2, scale=K ** -0.5)), rt(randn(M, N, seed=3))
     C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
     cs = torch.zeros(N, device=dev())
-    fused = split > 1 or M < 256          # the big-tile direct path leaves column sums to xvit_colsum
+    big = M >= 256 and ((M + 255) // 256) * ((N + 255) // 256) * split > 128   # dispatch rule of gemm.hip (use_big_tile)
+    fused = split > 1 or not big          # the big-tile direct path leaves column sums to xvit_colsum
     ops.gemm(ops.NN, dy.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, act=ops.ACT_DGELU, aux=z.to(dev(), torch.bfloat16),
              colsum=cs if fused else None, split_k=split)
     ref = (dy @ w) * _dgelu(z)
