@@ -302,8 +302,8 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
 // ------------------------------------------------------------------------------------------
 // delta[b,h,n] = sum_d dO * O
 // ------------------------------------------------------------------------------------------
-__global__ void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb, int64_t osn, float* __restrict__ delta,
-                                  int H, int N, int total) {
+__global__ void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb, int64_t osn, const float* __restrict__ lse,
+                                  float* __restrict__ delta, float* __restrict__ nlse, int H, int N, int total) {
   // 8 lanes per (b, h, n) row: each 16 B of O and dO
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int rowid = gid >> 3, part = gid & 7;
@@ -318,7 +318,10 @@ __global__ void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __rest
   acc += __shfl_xor(acc, 1);
   acc += __shfl_xor(acc, 2);
   acc += __shfl_xor(acc, 4);
-  if (rowid < total && part == 0) delta[rowid] = acc;
+  if (rowid < total && part == 0) {
+    delta[rowid] = acc;
+    nlse[rowid] = -lse[rowid] * LOG2E;   // the backward kernels compute P = exp2(s*c + nlse): ready for LDS-DMA, no per-tile transform
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -326,7 +329,7 @@ __global__ void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __rest
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                              int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             const float* __restrict__ nlse_ws, const float* __restrict__ delta,
                                                              bf16* __restrict__ dq, int H, int N, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
@@ -345,6 +348,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   bf16x8 qf[4], dof[4];
   load_lane_operand(qf, q + off, sn, q0, N, lane);
   load_lane_operand(dof, d_o + (int64_t)b * osb + head * DH, osn, q0, N, lane);
+  settle(qf);
+  settle(dof);
   ImgReader rd;
   rd.init(lane);
 
@@ -353,9 +358,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   const bool wave_active = q0 < N;   // wave-uniform
   const int64_t stat = ((int64_t)b * H + head) * N + qrow;
   const float c = scale * LOG2E;
-  // invalid query rows: lse = +big -> P = 0, so nothing is accumulated for them
-  const float nlse = valid ? -lse[stat] * LOG2E : -1e30f;
-  const float dlt = valid ? delta[stat] : 0.f;
+  // invalid query rows: nlse = -big -> P = 0, so nothing is accumulated for them
+  float nlse = valid ? nlse_ws[stat] : -1e30f;
+  float dlt = valid ? delta[stat] : 0.f;
+  asm volatile("" : "+v"(nlse), "+v"(dlt));   // settle these loads (and qf/dof below) before the tile loop: see settle()
 
   f32x16 dqacc[2];
 #pragma unroll
@@ -401,11 +407,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 // ------------------------------------------------------------------------------------------
 // backward, dK/dV: one wave = 32 keys, streams Q and dO tiles (+ lse, delta)
 // ------------------------------------------------------------------------------------------
-constexpr int DKV_STAGE = 2 * IMG_BYTES + 512;  // Q image | dO image | -lse*log2e[64] | delta[64]
+constexpr int DKV_STAGE = 2 * IMG_BYTES + 512;  // Q image | dO image | nlse[64] | delta[64]  (all four arrive by LDS-DMA)
 
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                               int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
-                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              const float* __restrict__ nlse_ws, const float* __restrict__ delta,
                                                               bf16* __restrict__ dk, bf16* __restrict__ dv, int H, int N, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
@@ -420,16 +426,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   TileLoader lq, ldo;
   lq.init(q + off, sn, N, wave, lane);
   ldo.init(d_o + ooff, osn, N, wave, lane);
+  // per-query statistics of a tile (64 floats each) also arrive by LDS-DMA (4 B per lane: wave 0 moves nlse, wave 1
+  // delta), so the loop contains NO ordinary global load whose compiler-inserted vmcnt(0) would drain the tile DMAs.
+  // Rows past N read as 0 (buffer bounds): nlse = 0 gives P = 1 there, harmless because dO = 0 and delta = 0.
+  const __amdgpu_buffer_rsrc_t rstat = make_rsrc((wave == 0 ? nlse_ws : delta) + stat0, clamp_bytes((int64_t)N * 4));
   auto stage_stats = [&](XVIT_LDS char* st, int tile) {
-    // 128 threads: [0,64) -> -lse*log2e, [64,128) -> delta, for the tile's 64 query rows
-    const int tid = threadIdx.x;
-    if (tid < 128) {
-      const int qi = tile * TILE_ROWS + (tid & 63);
-      float val;
-      if (tid < 64) val = qi < N ? -lse[stat0 + qi] * LOG2E : -1e30f;
-      else val = qi < N ? delta[stat0 + qi] : 0.f;
-      ((XVIT_LDS float*)(st + 2 * IMG_BYTES))[tid] = val;
-    }
+    if (wave < 2)
+      glds4(rstat, st + 2 * IMG_BYTES + wave * 256, (uint32_t)(lane * 4), (uint32_t)(tile * TILE_ROWS * 4));
   };
   lq.issue(smem, wave, 0);
   ldo.issue(smem + IMG_BYTES, wave, 0);
@@ -438,6 +441,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   bf16x8 kf[4], vf[4];
   load_lane_operand(kf, k + off, sn, k0, N, lane);
   load_lane_operand(vf, v + off, sn, k0, N, lane);
+  settle(kf);
+  settle(vf);
   ImgReader rd;
   rd.init(lane);
   const int h = lane >> 5;
@@ -532,11 +537,12 @@ extern "C" int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_
   if (int e = attn_check("xvit_attn_bwd", B, H, N, dh, sb, sn, osb, osn)) return e;
   hipStream_t s = (hipStream_t)stream;
   const int total = B * H * N;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, osb, osn, delta, H, N, total);
+  float* nlse = delta + total;   // workspace = [2][B,H,N]: delta | -lse*log2e
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, osb, osn, lse, delta, nlse, H, N, total);
   const dim3 grid((N + 127) / 128, H, B), block(256);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 2 * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
-                     osn, lse, delta, (bf16*)dk, (bf16*)dv, H, N, scale);
+                     osn, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 4 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb, osn,
-                     lse, delta, (bf16*)dq, H, N, scale);
+                     nlse, delta, (bf16*)dq, H, N, scale);
   return check_launch("xvit_attn_bwd");
 }

@@ -53,8 +53,29 @@ __device__ __forceinline__ uint32_t clamp_bytes(int64_t b) {
 }
 
 // 16-byte LDS-DMA: LDS[lds_base + lane*16 .. +16) <- buffer[voff + soff .. +16)
+//
+// Issued from inline asm on purpose.  With the __builtin_amdgcn_raw_ptr_buffer_load_lds form hipcc's
+// waitcnt pass cannot prove that a later ds_read_b64_tr_b16 does not alias the DMA destination and puts
+// `s_waitcnt vmcnt(0)` in front of the first transposed read of every iteration, which drains the
+// next-stage prefetch before any MFMA has issued (seen in the NN/TN GEMM and all attention loops).  The
+// kernels order DMA -> LDS read themselves (counted `s_waitcnt vmcnt` + s_barrier), so the compiler must
+// simply not model these loads.  Untracked VMEM ops can only make the compiler's own vmcnt waits
+// stricter, never weaker (the counter retires in order).  lds_base, soff and r must be wave-uniform.
+// M0 is written in the same statement that consumes it; nothing else in these kernels uses M0.
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, XVIT_LDS void* lds_base, uint32_t voff, uint32_t soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, lds_base, 16, voff, soff, 0, 0);
+  const uint32_t m0v = (uint32_t)(uintptr_t)lds_base;
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+               :
+               : "v"(voff), "s"(r), "s"(soff), "s"(m0v)
+               : "memory");
+}
+// 4-byte variant: LDS[lds_base + lane*4 .. +4) <- buffer[voff + soff .. +4)
+__device__ __forceinline__ void glds4(__amdgpu_buffer_rsrc_t r, XVIT_LDS void* lds_base, uint32_t voff, uint32_t soff) {
+  const uint32_t m0v = (uint32_t)(uintptr_t)lds_base;
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %0, %1, %2 offen lds"
+               :
+               : "v"(voff), "s"(r), "s"(soff), "s"(m0v)
+               : "memory");
 }
 
 __device__ __forceinline__ s16x4 lds_read_tr16(const XVIT_LDS void* p) {

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxvit_hip.so")
+LIB_PATH = os.environ.get("XVIT_LIB") or os.path.join(_HERE, "libxvit_hip.so")   # XVIT_LIB: A/B-test another build of the same ABI
 
 i32, i64, f32, u64, vp = C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_void_p
 

@@ -170,7 +170,7 @@ def attn_bwd(qkv, o, d_o, lse, B, N, H, scale):
     d = qkv.shape[1] // 3
     dh = d // H
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    delta = torch.empty(2, B, H, N, dtype=torch.float32, device=qkv.device)   # workspace: rowsum(do*o) | -lse*log2e
     ld = _rows2d(qkv)
     assert dqkv.stride(0) == ld and _rows2d(o) == d and _rows2d(d_o) == d
     p, g = qkv.data_ptr(), dqkv.data_ptr()

@@ -120,7 +120,7 @@ int xvit_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, const 
  * ---------------------------------------------------------------------------------------- */
 int xvit_attn_fwd(const void* q, const void* k, const void* v, int64_t stride_b, int64_t stride_n, void* o, int64_t o_stride_b,
                   int64_t o_stride_n, float* lse, int B, int H, int N, int dh, float scale, xvit_stream_t stream);
-/* delta[B,H,N] is caller-provided fp32 workspace (rowsum(do*o)).  dq/dk/dv use the q/k/v strides. */
+/* delta: caller-provided fp32 workspace of 2*B*H*N floats (rowsum(do*o), then -lse*log2e).  dq/dk/dv use the q/k/v strides. */
 int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t stride_b, int64_t stride_n, const void* o, const void* d_o,
                   int64_t o_stride_b, int64_t o_stride_n, const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H,
                   int N, int dh, float scale, xvit_stream_t stream);
