@@ -350,87 +350,134 @@ struct BigFrag {
   }
 };
 
-// ---- big-tile epilogue: branch-free, straight from the accumulators -----------------------------------
+// scheduling pattern of big_tile_mma: per step, the LDS reads issued in it, then its 4 MFMAs (the builtin wants literals)
+template <int S, int PF, int NA, int NB>
+__device__ __forceinline__ void mma_sched_steps() {
+  constexpr int reads = (S + PF < 16 ? NA : 0) + (S >= 4 && S < 8 ? NB : 0);
+  if constexpr (reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, reads, 0);
+  __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+  if constexpr (S + 1 < 16) mma_sched_steps<S + 1, PF, NA, NB>();
+}
+
+// One 256 x 256 x 64 K-tile for a wave's 128 x 64 sub-tile: 16 steps (2 k-halves x 8 row tiles) of 4 MFMAs.
+// The fragment reads are software-pipelined by hand: A fragments run PF steps ahead of their MFMAs, the
+// second k-half's B fragments are slipped in during steps 4..7, and sched_group_barrier pins that order.
+// (Left alone, hipcc folds all A fragments into ONE register and emits ds_read -> lgkmcnt(0) -> 4 MFMA
+// sixteen times per tile, exposing every LDS round trip; the main loop then sits at 49 % of the MFMA peak.)
+template <bool A_KS, bool B_KS>
+__device__ __forceinline__ void big_tile_mma(const XVIT_LDS char* sa, const XVIT_LDS char* sb, const BigFrag<A_KS, 8>& fa, const BigFrag<B_KS, 4>& fb,
+                                             f32x4 (&acc)[8][4]) {
+  constexpr int PF = 2;                       // prefetch distance in steps
+  constexpr int NA = A_KS ? 2 : 1, NB = B_KS ? 2 : 1;   // LDS instructions per fragment
+  bf16x8 b0[4], b1[4], a[16];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) b0[t] = fb.read(sb, t, 0);
+#pragma unroll
+  for (int s = 0; s < PF; ++s) a[s] = fa.read(sa, s & 7, s >> 3);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    if (s + PF < 16) a[s + PF] = fa.read(sa, (s + PF) & 7, (s + PF) >> 3);
+    if (s >= 4 && s < 8) b1[s - 4] = fb.read(sb, s - 4, 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc[s & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(s < 8 ? b0[j] : b1[j], a[s], acc[s & 7][j], 0, 0, 0);  // D'[n][m]
+  }
+  __builtin_amdgcn_sched_group_barrier(0x100, 4 * NB + PF * NA, 0);
+  mma_sched_steps<0, PF, NA, NB>();
+}
+
+// ---- big-tile epilogue: accumulators -> per-wave LDS transpose -> row-contiguous global accesses ----------
+// In the accumulators a lane owns 4 consecutive columns of rows (lane & 15) + 16 I: neighbouring lanes sit in
+// DIFFERENT rows, so a store straight from registers scatters 64 separate 8/16-byte pieces over 16 cache lines
+// (and the residual / aux loads likewise).  Each wave therefore bounces its 128 x 64 fp32 tile, 64 rows at a
+// time, through its own 16 KiB slice of the (now idle) stage buffers: written as [64 rows][16 chunks of 16 B]
+// with chunk ^= row & 15 (conflict-free for the column-wise writes and the row-wise reads), read back with 16
+// lanes per row.  One global instruction then covers 4 rows x 256 contiguous bytes (fp32) or 4 x 128 (bf16),
+// the bias is a per-lane constant, and a lane's rows advance by 4 per body, so the row -> offset maps
+// (residual row modulo, output segment gaps) are stepped incrementally instead of divided per body.
 // Every global access goes through a buffer resource with the out-of-range offset trick instead of a branch
-// (loads return 0, stores are dropped), so the 32 (row-tile, col-tile) bodies form one basic block and the
-// compiler batches the aux / residual loads instead of serialising 32 load->wait->compute->store rounds.
+// (loads return 0, stores are dropped), so the bodies form straight-line code and their loads batch.
 typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2_t;
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
 constexpr uint32_t OOB = 0xFFFFFFF0u;
+constexpr int EPI_WAVE_BYTES = 64 * 256;   // 64 rows x 64 fp32
 
 struct BigEpi {
-  __amdgpu_buffer_rsrc_t rc, raux, rres, rbias, rslab;
-  int row0, col0;
+  __amdgpu_buffer_rsrc_t rc, raux, rres, rslab;
   bool has_res, has_aux, to_slab;
+  uint32_t col;            // this lane's first output column (4 consecutive)
+  bool col_ok;
+  f32x4 bias;
   uint64_t drop_base;
+  // state of the lane's current row, advanced by 4 rows per body (32-bit byte offsets: the host guarantees
+  // every addressed tensor stays below 2 GiB per batch)
+  uint32_t row, c, aux, res, slab;
+  uint32_t rrem, rmod, srem, smod;         // row % res_row_mod, row % seg_rows and their moduli (huge when unused)
+  uint32_t c_step, aux_step, res_step, slab_step, c_gap, res_wrap;
 };
 
-// per-row byte offsets (32-bit: the host guarantees every addressed tensor stays below 2 GiB per batch)
-struct RowOff { uint32_t c, aux, res, slab; bool ok; uint32_t row; };
-
-template <int ACT, bool DROP, int I, int J>
-__device__ __forceinline__ void big_epi_one(const GemmParams& p, const BigEpi& e, const RowOff& r, const f32x4 (&acc)[8][4]) {
-  const uint32_t col = (uint32_t)(e.col0 + J * 16);
-  const bool ok = r.ok && col < (uint32_t)p.N;
-  f32x4 v = acc[I][J];
+template <int ACT, bool DROP>
+__device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32x4 v) {
+  const bool ok = e.col_ok && e.row < (uint32_t)p.M;
   if (e.to_slab) {   // split-K partial sums, [M][N] fp32
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rslab, ok ? r.slab + col * 4 : OOB, 0, 0);
-    return;
-  }
-  v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rbias, col * 4, 0, 0));   // zero-size descriptor when there is no bias
-  if (ACT == XVIT_ACT_GELU) {
-    if (e.has_aux) {
-      bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, z), e.raux, ok ? r.aux + col * 2 : OOB, 0, 0);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
-  } else if (ACT == XVIT_ACT_DGELU) {
-    const bf16x4 z = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(e.raux, ok ? r.aux + col * 2 : OOB, 0, 0));
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] *= dgelu_f(bf2f(z[c]));
-  }
-  if (DROP) {
-    const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
-    const uint64_t idx = e.drop_base + (uint64_t)r.row * p.N + col;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = (hash32(p.drop_seed, idx + c) & 0xFFFFFFu) >= thr ? v[c] * p.drop_inv : 0.f;
-  }
-  if (e.has_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rres, ok ? r.res + col * 4 : OOB, 0, 0));
-  if (p.c_f32) {
-    const uint32_t off = ok ? r.c + col * 4 : OOB;
-    if (p.accumulate) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rc, off, 0, 0));
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rc, off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rslab, ok ? e.slab : OOB, 0, 0);
   } else {
-    bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), e.rc, ok ? r.c + col * 2 : OOB, 0, 0);
+    v += e.bias;
+    if (ACT == XVIT_ACT_GELU) {
+      if (e.has_aux) {
+        bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, z), e.raux, ok ? e.aux : OOB, 0, 0);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
+    } else if (ACT == XVIT_ACT_DGELU) {
+      const bf16x4 z = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(e.raux, ok ? e.aux : OOB, 0, 0));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] *= dgelu_f(bf2f(z[c]));
+    }
+    if (DROP) {
+      const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+      const uint64_t idx = e.drop_base + (uint64_t)e.row * p.N + e.col;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = (hash32(p.drop_seed, idx + c) & 0xFFFFFFu) >= thr ? v[c] * p.drop_inv : 0.f;
+    }
+    if (e.has_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rres, ok ? e.res : OOB, 0, 0));
+    if (p.c_f32) {
+      const uint32_t off = ok ? e.c : OOB;
+      if (p.accumulate) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rc, off, 0, 0));
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rc, off, 0, 0);
+    } else {
+      bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), e.rc, ok ? e.c : OOB, 0, 0);
+    }
   }
+  // next body: 4 rows further down
+  e.row += 4; e.c += e.c_step; e.aux += e.aux_step; e.res += e.res_step; e.slab += e.slab_step;
+  e.rrem += 4; e.srem += 4;
+  if (e.rrem >= e.rmod) { e.rrem -= e.rmod; e.res -= e.res_wrap; }
+  if (e.srem >= e.smod) { e.srem -= e.smod; e.c += e.c_gap; }
 }
-template <int ACT, bool DROP, int I>
-__device__ __forceinline__ void big_epi_row(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4]) {
-  RowOff r;
-  r.row = (uint32_t)(e.row0 + I * 16);
-  r.ok = r.row < (uint32_t)p.M;
-  const uint32_t rr = p.res_row_mod > 0 ? (uint32_t)p.res_row_off + r.row % (uint32_t)p.res_row_mod : r.row;
-  const uint32_t orow = p.seg_rows > 0 ? r.row + (r.row / (uint32_t)p.seg_rows) * (uint32_t)p.seg_skip + (uint32_t)p.row_off : r.row;
-  r.c = orow * (uint32_t)p.ldc * (p.c_f32 ? 4u : 2u);
-  r.aux = r.row * (uint32_t)p.ldaux * 2u;
-  r.res = rr * (uint32_t)p.ldr * 4u;
-  r.slab = r.row * (uint32_t)p.N * 4u;
-  big_epi_one<ACT, DROP, I, 0>(p, e, r, acc); big_epi_one<ACT, DROP, I, 1>(p, e, r, acc);
-  big_epi_one<ACT, DROP, I, 2>(p, e, r, acc); big_epi_one<ACT, DROP, I, 3>(p, e, r, acc);
+
+// rows 64 HALF .. 64 HALF + 63 of the wave's tile: accumulators -> LDS (column-wise) -> 16 bodies (row-wise)
+template <int ACT, bool DROP, int HALF>
+__device__ __forceinline__ void big_epi_half(const GemmParams& p, BigEpi& e, const f32x4 (&acc)[8][4], XVIT_LDS char* slice, const uint32_t (&woff)[4],
+                                             const uint32_t (&roff)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *(XVIT_LDS f32x4*)(slice + i * 4096 + woff[j]) = acc[HALF * 4 + i][j];
+#pragma unroll
+  for (int it = 0; it < 16; ++it) {
+    const f32x4 v = *(const XVIT_LDS f32x4*)(slice + it * 1024 + roff[it & 3]);
+    big_epi_body<ACT, DROP>(p, e, v);
+    if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 4 bodies (4-8 loads in flight) per scheduling region
+  }
 }
 template <int ACT, bool DROP>
-__device__ __forceinline__ void big_epilogue(const GemmParams& p, const BigEpi& e, const f32x4 (&acc)[8][4]) {
-  // one row-tile (4 bodies, 4-8 loads in flight) per scheduling region
-  big_epi_row<ACT, DROP, 0>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
-  big_epi_row<ACT, DROP, 1>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
-  big_epi_row<ACT, DROP, 2>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
-  big_epi_row<ACT, DROP, 3>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
-  big_epi_row<ACT, DROP, 4>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
-  big_epi_row<ACT, DROP, 5>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
-  big_epi_row<ACT, DROP, 6>(p, e, acc); __builtin_amdgcn_sched_barrier(0);
-  big_epi_row<ACT, DROP, 7>(p, e, acc);
+__device__ __forceinline__ void big_epilogue(const GemmParams& p, BigEpi& e, const f32x4 (&acc)[8][4], XVIT_LDS char* slice, const uint32_t (&woff)[4],
+                                             const uint32_t (&roff)[4]) {
+  big_epi_half<ACT, DROP, 0>(p, e, acc, slice, woff, roff);
+  big_epi_half<ACT, DROP, 1>(p, e, acc, slice, woff, roff);
 }
 
 template <bool A_KS, bool B_KS>
@@ -450,6 +497,11 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin + BK - 1) / BK;   // may be 0 for a trailing split: still writes its (zero) slab
 
+#ifdef XVIT_DEBUG_TIMES
+  uint64_t tstamp[5];
+  tstamp[0] = wall_clock64(); tstamp[1] = 0;
+  uint64_t itv[3] = {0, 0, 0}, itprev = 0;
+#endif
   BigLoader<A_KS> la;
   BigLoader<B_KS> lb;
   {
@@ -478,33 +530,37 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef XVIT_DEBUG_TIMES
+    if (kt == 0) tstamp[1] = wall_clock64();
+    uint64_t it0 = __builtin_readcyclecounter();
+#endif
+#ifndef XVIT_DEBUG_NO_DMA
     if (kt + 1 < nk) {
       XVIT_LDS char* nxt = smem + ((kt + 1) & 1) * T_STAGE;
       la.issue(nxt, wave, kt + 1);
       lb.issue(nxt + T_OPER, wave, kt + 1);
     }
+#endif
     const XVIT_LDS char* sa = smem + (kt & 1) * T_STAGE;
     const XVIT_LDS char* sb = sa + T_OPER;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 bfr[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) bfr[t] = fb.read(sb, t, kk);
-#pragma unroll
-      for (int mh = 0; mh < 2; ++mh) {
-        bf16x8 af[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) af[t] = fa.read(sa, mh * 4 + t, kk);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[mh * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[mh * 4 + i][j], 0, 0, 0);  // D'[n][m]
-      }
-    }
+#ifdef XVIT_DEBUG_TIMES
+    uint64_t it1 = __builtin_readcyclecounter();
+#endif
+#ifndef XVIT_DEBUG_NO_MMA
+    big_tile_mma<A_KS, B_KS>(sa, sb, fa, fb, acc);
+#endif
+#ifdef XVIT_DEBUG_TIMES
+    if (kt == 4) { itv[0] = it1 - it0; itv[1] = __builtin_readcyclecounter() - it1; }
+    if (kt == 5) { itv[2] = it0 - itprev; }
+    itprev = __builtin_readcyclecounter();
+#endif
   }
 
-  // ---------------- epilogue straight from the accumulators ------------------------------------
+  // ---------------- epilogue: per-wave LDS transpose, then row-contiguous global accesses ---------------
+#ifdef XVIT_DEBUG_TIMES
+  tstamp[2] = wall_clock64();
+#endif
+  __syncthreads();   // every wave is done reading the last stage: the stage buffers become the transpose slices
   const int nbatch = gridDim.z / p.split_k;
   BigEpi e;
   const int64_t celt = p.c_f32 ? 4 : 2;
@@ -513,24 +569,78 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   const bool has_bias = p.bias != nullptr;
   e.raux = make_rsrc(e.has_aux ? (const void*)(p.aux + batch * p.sAux) : (const void*)p.C, e.has_aux ? 0x7FFFFFF0u : 0u);
   e.rres = make_rsrc(e.has_res ? (const void*)(p.res + batch * p.sR) : (const void*)p.C, e.has_res ? 0x7FFFFFF0u : 0u);
-  e.rbias = make_rsrc(has_bias ? (const void*)(p.bias + batch * p.sBias) : (const void*)p.C, has_bias ? (uint32_t)(p.N * 4) : 0u);
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(has_bias ? (const void*)(p.bias + batch * p.sBias) : (const void*)p.C, has_bias ? (uint32_t)(p.N * 4) : 0u);
   e.rslab = make_rsrc(e.to_slab ? (const void*)(p.slab + ((int64_t)split * nbatch + batch) * (int64_t)p.M * p.N) : (const void*)p.C,
                       e.to_slab ? clamp_bytes((int64_t)p.M * p.N * 4) : 0u);
   // the epilogue's address arithmetic is loop-invariant: without this opaque dependency (placed AFTER the K loop)
-  // LLVM hoists ~100 registers of offsets above the MFMA loop and spills the accumulators
+  // LLVM hoists it above the MFMA loop and spills the accumulators
   int pin = 0;
   asm volatile("" : "+v"(pin));
-  e.row0 = m0 + wr * 128 + (lane & 15) + pin;
-  e.col0 = n0 + wc * 64 + (lane >> 4) * 4 + pin;
+  const int wl = lane + pin;
+  // LDS slice offsets: accumulator layout (row r = lane & 15 of each 16-row tile, chunk 4 J + g) and read-back
+  // layout (row 4 it + rr, chunk k), both with chunk ^= row & 15
+  uint32_t woff[4], roff[4];
+  {
+    const int r = wl & 15, g = wl >> 4, k = wl & 15, rr = wl >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = (uint32_t)(r * 256 + (((j * 4 + g) ^ r) << 4));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) roff[q] = (uint32_t)(rr * 256 + ((k ^ (q * 4 + rr)) << 4));
+  }
+  XVIT_LDS char* slice = smem + wave * EPI_WAVE_BYTES;
+  e.col = (uint32_t)(n0 + wc * 64 + (wl & 15) * 4);
+  e.col_ok = e.col < (uint32_t)p.N;
+#ifdef XVIT_DEBUG_NOSTORE
+  e.col_ok = e.col_ok && pin != 0;
+#endif
+  e.bias = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, e.col * 4, 0, 0));   // zero-size descriptor when there is no bias
   e.drop_base = (uint64_t)batch * ((uint64_t)p.M * p.N);
+  e.row = (uint32_t)(m0 + wr * 128 + (wl >> 4));
+  {
+    const bool rmap = p.res_row_mod > 0, smap = p.seg_rows > 0;
+    e.rmod = rmap ? (uint32_t)p.res_row_mod : 0x7FFFFFFFu;
+    e.smod = smap ? (uint32_t)p.seg_rows : 0x7FFFFFFFu;
+    e.rrem = rmap ? e.row % e.rmod : e.row;
+    e.srem = smap ? e.row % e.smod : e.row;
+    const uint32_t rrow = rmap ? (uint32_t)p.res_row_off + e.rrem : e.row;
+    const uint32_t orow = smap ? e.row + (e.row / e.smod) * (uint32_t)p.seg_skip + (uint32_t)p.row_off : e.row;
+    const uint32_t ce = p.c_f32 ? 4u : 2u;
+    e.c = orow * (uint32_t)p.ldc * ce + e.col * ce;
+    e.aux = e.row * (uint32_t)p.ldaux * 2u + e.col * 2u;
+    e.res = rrow * (uint32_t)p.ldr * 4u + e.col * 4u;
+    e.slab = e.row * (uint32_t)p.N * 4u + e.col * 4u;
+    e.c_step = 4u * (uint32_t)p.ldc * ce;
+    e.aux_step = 4u * (uint32_t)p.ldaux * 2u;
+    e.res_step = 4u * (uint32_t)p.ldr * 4u;
+    e.slab_step = 4u * (uint32_t)p.N * 4u;
+    e.c_gap = smap ? (uint32_t)p.seg_skip * (uint32_t)p.ldc * ce : 0u;
+    e.res_wrap = rmap ? e.rmod * (uint32_t)p.ldr * 4u : 0u;
+  }
+#ifdef XVIT_DEBUG_TIMES
+  tstamp[3] = wall_clock64();
+#endif
   // one specialised, fully unrolled copy per (activation, dropout): every acc[][] index is a compile-time constant
   if (p.drop_p > 0.f) {
-    if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, true>(p, e, acc);
-    else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, true>(p, e, acc);
-    else big_epilogue<XVIT_ACT_NONE, true>(p, e, acc);
-  } else if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, false>(p, e, acc);
-  else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, false>(p, e, acc);
-  else big_epilogue<XVIT_ACT_NONE, false>(p, e, acc);
+    if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, true>(p, e, acc, slice, woff, roff);
+    else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, true>(p, e, acc, slice, woff, roff);
+    else big_epilogue<XVIT_ACT_NONE, true>(p, e, acc, slice, woff, roff);
+  } else if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, false>(p, e, acc, slice, woff, roff);
+  else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, false>(p, e, acc, slice, woff, roff);
+  else big_epilogue<XVIT_ACT_NONE, false>(p, e, acc, slice, woff, roff);
+#ifdef XVIT_DEBUG_TIMES
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  tstamp[4] = wall_clock64();
+  if (p.colsum && threadIdx.x == 0) {
+    uint64_t* dst = (uint64_t*)p.colsum + (size_t)blockIdx.x * 8;
+    for (int i = 0; i < 5; ++i) dst[i] = tstamp[i];
+    dst[5] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 4 /*HW_ID*/ );   // wave/simd/cu/se ids
+    dst[6] = wall_clock64();
+  }
+  if (p.colsum && lane == 0) {   // per-wave: cycles spent issuing the DMAs, in the MFMA section, and waiting at the top (iteration 4 -> 5)
+    uint64_t* dw = (uint64_t*)p.colsum + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 8 + wave) * 4;
+    dw[0] = itv[0]; dw[1] = itv[1]; dw[2] = itv[2];
+  }
+#endif
 }
 
 // split-K second pass: sum the partial tiles in a fixed order (bit-reproducible), then the full epilogue
@@ -618,7 +728,9 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   p.seg_rows = a->out_seg_rows; p.seg_skip = a->out_seg_skip; p.row_off = a->out_row_off;
   p.slab = ws_need > 0 ? (float*)a->workspace : nullptr;
   p.colsum = a->colsum;
+#ifndef XVIT_DEBUG_TIMES
   XVIT_REQUIRE(!a->colsum || !use_big_tile(a) || a->split_k > 1, "xvit_gemm: colsum is provided by the small-tile and split-K paths only (use xvit_colsum for large outputs)");
+#endif
   XVIT_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "xvit_gemm: dropout_p must be in [0, 1)");
   p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
   hipStream_t s = (hipStream_t)stream;

@@ -408,3 +408,29 @@ extern "C" int xvit_resize_pad_crop_i16(const void* src_i16, void* dst_bf16, int
                      Ds, Hs, Ws, D, H, W, offset(Ds, D), offset(Hs, H), offset(Ws, W), pad_value, total);
   return xvit::check_launch("xvit_resize_pad_crop_i16");
 }
+
+// ------------------------------------------------------------------------------------------
+// Placement trace: where does the dispatcher put the workgroups of a stream?  Each block records its XCC
+// (XCD) id and HW_ID, then lingers ~`linger_us` so that the launch spreads over every CU the stream may
+// use.  Used to map hipExtStreamCreateWithCUMask bits to XCDs and to check the blockIdx -> XCD round-robin
+// the GEMM tile remap assumes.
+// ------------------------------------------------------------------------------------------
+namespace xvit {
+__global__ void cu_trace_kernel(uint32_t* __restrict__ out, int linger_us) {
+  if (threadIdx.x == 0) {
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    out[2 * blockIdx.x] = xcc;
+    out[2 * blockIdx.x + 1] = hw;
+  }
+  const uint64_t t0 = wall_clock64();   // 100 MHz
+  while (wall_clock64() - t0 < (uint64_t)linger_us * 100) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace xvit
+
+extern "C" int xvit_cu_trace(uint32_t* out, int nblocks, int linger_us, xvit_stream_t stream) {
+  XVIT_REQUIRE(out && nblocks > 0 && linger_us >= 0 && linger_us <= 10000, "xvit_cu_trace: bad arguments");
+  hipLaunchKernelGGL(xvit::cu_trace_kernel, dim3((unsigned)nblocks), dim3(64), 0, (hipStream_t)stream, out, linger_us);
+  return xvit::check_launch("xvit_cu_trace");
+}

@@ -163,7 +163,12 @@ class MultiScaleBlock(nn.Module):
     def _branch_streams(cls, device, n):
         key = (device, n)
         if key not in cls._streams:
-            cls._streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+            if os.environ.get("XVIT_CU_SPLIT", "0") == "1":   # each branch owns 1/n of the CUs (see xvit/cu_mask.py)
+                from . import cu_mask
+                n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+                cls._streams[key] = [cu_mask.masked_stream(device, bits) for bits in cu_mask.split_masks(n_cu, n)]
+            else:
+                cls._streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
         return cls._streams[key]
 
     def _branches(self, x):

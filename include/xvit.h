@@ -172,6 +172,11 @@ int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, i
  * y = x * keep / (1-p).  In-place allowed.  dtype XVIT_BF16 | XVIT_F32. */
 int xvit_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, xvit_stream_t stream);
 
+/* Diagnostic (no reference counterpart): out[2*b] = XCC (XCD) id and out[2*b+1] = HW_ID register of the CU
+   that ran workgroup b of an `nblocks`-block launch on `stream`; every block lingers `linger_us` so the
+   launch spreads over all CUs the stream may use.  Maps CU-mask bits of a masked stream to XCDs. */
+int xvit_cu_trace(uint32_t* out, int nblocks, int linger_us, xvit_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused multi-tensor Adam step with torch.optim.Adam semantics (model_cross.py:276-278: L2 weight decay added to
  * the gradient, bias correction with `step`, eps outside the square root).  table_dev: device array of
