@@ -364,9 +364,14 @@ __device__ __forceinline__ void mma_sched_steps() {
 // second k-half's B fragments are slipped in during steps 4..7, and sched_group_barrier pins that order.
 // (Left alone, hipcc folds all A fragments into ONE register and emits ds_read -> lgkmcnt(0) -> 4 MFMA
 // sixteen times per tile, exposing every LDS round trip; the main loop then sits at 49 % of the MFMA peak.)
+// The 8 LDS-DMA instructions that prefetch the next K-tile are issued one per step in steps 0..7 (`ra` / `rb`
+// are zero-size descriptors in the last iteration): issued back to back at the top of the iteration they
+// stall the wave ~670 cycles in the in-order vector-memory issue queue before its first MFMA (same-box A/B: one
+// per step -3 % on the model's 15 GEMM shapes; two per step or every other step are both slower than that).
 template <bool A_KS, bool B_KS>
 __device__ __forceinline__ void big_tile_mma(const XVIT_LDS char* sa, const XVIT_LDS char* sb, const BigFrag<A_KS, 8>& fa, const BigFrag<B_KS, 4>& fb,
-                                             f32x4 (&acc)[8][4]) {
+                                             f32x4 (&acc)[8][4], const BigLoader<A_KS>& la, const BigLoader<B_KS>& lb, __amdgpu_buffer_rsrc_t ra,
+                                             __amdgpu_buffer_rsrc_t rb, XVIT_LDS char* nxt, int wave, uint32_t soff_a, uint32_t soff_b) {
   constexpr int PF = 2;                       // prefetch distance in steps
   constexpr int NA = A_KS ? 2 : 1, NB = B_KS ? 2 : 1;   // LDS instructions per fragment
   bf16x8 b0[4], b1[4], a[16];
@@ -376,6 +381,10 @@ __device__ __forceinline__ void big_tile_mma(const XVIT_LDS char* sa, const XVIT
   for (int s = 0; s < PF; ++s) a[s] = fa.read(sa, s & 7, s >> 3);
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
+#ifndef XVIT_DEBUG_NO_DMA
+    if (s < 4) glds16(ra, nxt + (wave * 4 + s) * 1024, la.voff[s], soff_a);
+    else if (s < 8) glds16(rb, nxt + T_OPER + (wave * 4 + s - 4) * 1024, lb.voff[s - 4], soff_b);
+#endif
     if (s + PF < 16) a[s + PF] = fa.read(sa, (s + PF) & 7, (s + PF) >> 3);
     if (s >= 4 && s < 8) b1[s - 4] = fb.read(sb, s - 4, 1);
 #pragma unroll
@@ -523,6 +532,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const __amdgpu_buffer_rsrc_t null_rsrc = make_rsrc(p.A, 0u);   // every access out of range: the DMA fills zeros, fetches nothing
   if (nk > 0) {
     la.issue(smem, wave, 0);
     lb.issue(smem + T_OPER, wave, 0);
@@ -534,20 +544,16 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
     if (kt == 0) tstamp[1] = wall_clock64();
     uint64_t it0 = __builtin_readcyclecounter();
 #endif
-#ifndef XVIT_DEBUG_NO_DMA
-    if (kt + 1 < nk) {
-      XVIT_LDS char* nxt = smem + ((kt + 1) & 1) * T_STAGE;
-      la.issue(nxt, wave, kt + 1);
-      lb.issue(nxt + T_OPER, wave, kt + 1);
-    }
-#endif
+    const bool more = kt + 1 < nk;
+    XVIT_LDS char* nxt = smem + ((kt + 1) & 1) * T_STAGE;
     const XVIT_LDS char* sa = smem + (kt & 1) * T_STAGE;
     const XVIT_LDS char* sb = sa + T_OPER;
 #ifdef XVIT_DEBUG_TIMES
     uint64_t it1 = __builtin_readcyclecounter();
 #endif
 #ifndef XVIT_DEBUG_NO_MMA
-    big_tile_mma<A_KS, B_KS>(sa, sb, fa, fb, acc);
+    big_tile_mma<A_KS, B_KS>(sa, sb, fa, fb, acc, la, lb, more ? la.rsrc : null_rsrc, more ? lb.rsrc : null_rsrc, nxt, wave,
+                             (uint32_t)(kt + 1) * la.kstep, (uint32_t)(kt + 1) * lb.kstep);
 #endif
 #ifdef XVIT_DEBUG_TIMES
     if (kt == 4) { itv[0] = it1 - it0; itv[1] = __builtin_readcyclecounter() - it1; }
@@ -556,6 +562,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 #endif
   }
 
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last iteration's (zero-fill) DMAs have landed before the stage buffers are recycled
   // ---------------- epilogue: per-wave LDS transpose, then row-contiguous global accesses ---------------
 #ifdef XVIT_DEBUG_TIMES
   tstamp[2] = wall_clock64();
