@@ -111,6 +111,24 @@ __device__ __forceinline__ void settle(bf16x8 (&f)[4]) {
   }
 }
 
+// counted wait on the vector-memory counter (the LDS-DMA ring: "at most N loads still in flight")
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// top-of-iteration wait of an NST-deep ring whose waves issue PT DMA instructions per tile: tile t must have
+// landed, the (up to NST-2) younger tiles may stay in flight
+template <int NST, int PT>
+__device__ __forceinline__ void ring_wait(int t, int ntiles) {
+  const int ahead = min(NST - 2, ntiles - 1 - t);
+  if (NST >= 4 && ahead == 2) wait_vmcnt<2 * PT>();
+  else if (NST >= 3 && ahead >= 1) wait_vmcnt<PT>();
+  else wait_vmcnt<0>();
+}
+#ifndef XVIT_BWD_NST
+#define XVIT_BWD_NST 2
+#endif
+constexpr int BWD_NST = XVIT_BWD_NST;      // K/V (dQ kernel) and Q/dO (dK/dV kernel) ring depth of the backward kernels.
+                                         // Same-box A/B at N = 512..4097: depth 2, 3 and 4 are within noise (the loops are not load-latency-bound)
+
 #define ZERO16 (f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f})
 
 // element index inside a 32-row accumulator block held in register i by lane half h
@@ -342,8 +360,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   TileLoader lk, lv;
   lk.init(k + off, sn, N, wave, lane);
   lv.init(v + off, sn, N, wave, lane);
-  lk.issue(smem, wave, 0);
-  lv.issue(smem + IMG_BYTES, wave, 0);
+#pragma unroll
+  for (int st = 0; st < BWD_NST - 1; ++st)
+    if (st < ntiles) {
+      lk.issue(smem + st * 2 * IMG_BYTES, wave, st);
+      lv.issue(smem + st * 2 * IMG_BYTES + IMG_BYTES, wave, st);
+    }
 
   bf16x8 qf[4], dof[4];
   load_lane_operand(qf, q + off, sn, q0, N, lane);
@@ -367,16 +389,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
 
+  int stage = 0;
   for (int t = 0; t < ntiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < ntiles) {
-      XVIT_LDS char* nxt = smem + ((t + 1) & 1) * 2 * IMG_BYTES;
-      lk.issue(nxt, wave, t + 1);
-      lv.issue(nxt + IMG_BYTES, wave, t + 1);
+    ring_wait<BWD_NST, 4>(t, ntiles);
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of tile t are in LDS; every wave is done with tile t-1
+    if (t + BWD_NST - 1 < ntiles) {
+      int ns = stage + BWD_NST - 1;
+      if (ns >= BWD_NST) ns -= BWD_NST;
+      lk.issue(smem + ns * 2 * IMG_BYTES, wave, t + BWD_NST - 1);
+      lv.issue(smem + ns * 2 * IMG_BYTES + IMG_BYTES, wave, t + BWD_NST - 1);
     }
-    const XVIT_LDS char* kimg = smem + (t & 1) * 2 * IMG_BYTES;
+    const XVIT_LDS char* kimg = smem + stage * 2 * IMG_BYTES;
     const XVIT_LDS char* vimg = kimg + IMG_BYTES;
+    stage = stage + 1 == BWD_NST ? 0 : stage + 1;
     if (!wave_active) continue;
     const int nkb = (N - t * TILE_ROWS) > 32 ? 2 : 1;   // a tail tile with <= 32 keys needs one key block only
 #pragma unroll
@@ -426,17 +451,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   TileLoader lq, ldo;
   lq.init(q + off, sn, N, wave, lane);
   ldo.init(d_o + ooff, osn, N, wave, lane);
-  // per-query statistics of a tile (64 floats each) also arrive by LDS-DMA (4 B per lane: wave 0 moves nlse, wave 1
+  // per-query statistics of a tile (64 floats each) also arrive by LDS-DMA (4 B per lane: even waves move nlse, odd waves
   // delta), so the loop contains NO ordinary global load whose compiler-inserted vmcnt(0) would drain the tile DMAs.
   // Rows past N read as 0 (buffer bounds): nlse = 0 gives P = 1 there, harmless because dO = 0 and delta = 0.
-  const __amdgpu_buffer_rsrc_t rstat = make_rsrc((wave == 0 ? nlse_ws : delta) + stat0, clamp_bytes((int64_t)N * 4));
-  auto stage_stats = [&](XVIT_LDS char* st, int tile) {
-    if (wave < 2)
-      glds4(rstat, st + 2 * IMG_BYTES + wave * 256, (uint32_t)(lane * 4), (uint32_t)(tile * TILE_ROWS * 4));
+  const __amdgpu_buffer_rsrc_t rstat = make_rsrc(((wave & 1) == 0 ? nlse_ws : delta) + stat0, clamp_bytes((int64_t)N * 4));
+  auto stage_stats = [&](XVIT_LDS char* st, int tile) {   // waves 2, 3 repeat waves 0, 1 (same bytes): every wave issues 5 DMAs per tile
+    glds4(rstat, st + 2 * IMG_BYTES + (wave & 1) * 256, (uint32_t)(lane * 4), (uint32_t)(tile * TILE_ROWS * 4));
   };
-  lq.issue(smem, wave, 0);
-  ldo.issue(smem + IMG_BYTES, wave, 0);
-  stage_stats(smem, 0);
+#pragma unroll
+  for (int st = 0; st < BWD_NST - 1; ++st)
+    if (st < ntiles) {
+      lq.issue(smem + st * DKV_STAGE, wave, st);
+      ldo.issue(smem + st * DKV_STAGE + IMG_BYTES, wave, st);
+      stage_stats(smem + st * DKV_STAGE, st);
+    }
 
   bf16x8 kf[4], vf[4];
   load_lane_operand(kf, k + off, sn, k0, N, lane);
@@ -453,16 +481,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
 
+  int stage = 0;
   for (int t = 0; t < ntiles; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < ntiles) {
-      XVIT_LDS char* nxt = smem + ((t + 1) & 1) * DKV_STAGE;
-      lq.issue(nxt, wave, t + 1);
-      ldo.issue(nxt + IMG_BYTES, wave, t + 1);
-      stage_stats(nxt, t + 1);
+    ring_wait<BWD_NST, 5>(t, ntiles);
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of tile t are in LDS; every wave is done with tile t-1
+    if (t + BWD_NST - 1 < ntiles) {
+      int ns = stage + BWD_NST - 1;
+      if (ns >= BWD_NST) ns -= BWD_NST;
+      XVIT_LDS char* nxt = smem + ns * DKV_STAGE;
+      lq.issue(nxt, wave, t + BWD_NST - 1);
+      ldo.issue(nxt + IMG_BYTES, wave, t + BWD_NST - 1);
+      stage_stats(nxt, t + BWD_NST - 1);
     }
-    const XVIT_LDS char* qimg = smem + (t & 1) * DKV_STAGE;
+    const XVIT_LDS char* qimg = smem + stage * DKV_STAGE;
+    stage = stage + 1 == BWD_NST ? 0 : stage + 1;
     const XVIT_LDS char* doimg = qimg + IMG_BYTES;
     const XVIT_LDS float* st_lse = (const XVIT_LDS float*)(qimg + 2 * IMG_BYTES);
     const XVIT_LDS float* st_dlt = st_lse + 64;
@@ -536,13 +568,19 @@ extern "C" int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_
   XVIT_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "xvit_attn_bwd: null pointer");
   if (int e = attn_check("xvit_attn_bwd", B, H, N, dh, sb, sn, osb, osn)) return e;
   hipStream_t s = (hipStream_t)stream;
+  static const bool lds_opt_in = [] {   // rings deeper than 3 stages need more than the default 64 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * DKV_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * 2 * IMG_BYTES);
+    return true;
+  }();
+  (void)lds_opt_in;
   const int total = B * H * N;
   float* nlse = delta + total;   // workspace = [2][B,H,N]: delta | -lse*log2e
   hipLaunchKernelGGL(attn_delta_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, osb, osn, lse, delta, nlse, H, N, total);
   const dim3 grid((N + 127) / 128, H, B), block(256);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 2 * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, BWD_NST * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
                      osn, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 4 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb, osn,
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb, osn,
                      nlse, delta, (bf16*)dq, H, N, scale);
   return check_launch("xvit_attn_bwd");
 }
