@@ -417,6 +417,8 @@ struct BigEpi {
   uint32_t col;            // this lane's first output column (4 consecutive)
   bool col_ok;
   f32x4 bias;
+  f32x4 csum;              // running column sums of the values this lane stored (for p.colsum)
+  float* colsum_dst;       // p.colsum + batch offset + this lane's first column
   uint64_t drop_base;
   // state of the lane's current row, advanced by 4 rows per body (32-bit byte offsets: the host guarantees
   // every addressed tensor stays below 2 GiB per batch)
@@ -459,6 +461,8 @@ __device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32
       bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), e.rc, ok ? e.c : OOB, 0, 0);
     }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) e.csum[c] += ok ? v[c] : 0.f;   // the lane's 4 columns are the same in every body
   }
   // next body: 4 rows further down
   e.row += 4; e.c += e.c_step; e.aux += e.aux_step; e.res += e.res_step; e.slab += e.slab_step;
@@ -487,6 +491,21 @@ __device__ __forceinline__ void big_epilogue(const GemmParams& p, BigEpi& e, con
                                              const uint32_t (&roff)[4]) {
   big_epi_half<ACT, DROP, 0>(p, e, acc, slice, woff, roff);
   big_epi_half<ACT, DROP, 1>(p, e, acc, slice, woff, roff);
+#ifndef XVIT_DEBUG_TIMES   // (that build borrows p.colsum as its timestamp buffer)
+  if (p.colsum && !e.to_slab) {   // += column sums of the stored tile: lanes l, l+16, l+32, l+48 share their 4 columns
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float t = e.csum[c];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      e.csum[c] = t;
+    }
+    if ((threadIdx.x & 63) < 16 && e.col_ok) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) unsafeAtomicAdd(e.colsum_dst + c, e.csum[c]);
+    }
+  }
+#endif
 }
 
 template <bool A_KS, bool B_KS>
@@ -602,6 +621,8 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 #endif
   e.bias = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, e.col * 4, 0, 0));   // zero-size descriptor when there is no bias
   e.drop_base = (uint64_t)batch * ((uint64_t)p.M * p.N);
+  e.csum = f32x4{0.f, 0.f, 0.f, 0.f};
+  e.colsum_dst = p.colsum ? p.colsum + batch * p.sBias + e.col : nullptr;
   e.row = (uint32_t)(m0 + wr * 128 + (wl >> 4));
   {
     const bool rmap = p.res_row_mod > 0, smap = p.seg_rows > 0;
@@ -735,9 +756,6 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   p.seg_rows = a->out_seg_rows; p.seg_skip = a->out_seg_skip; p.row_off = a->out_row_off;
   p.slab = ws_need > 0 ? (float*)a->workspace : nullptr;
   p.colsum = a->colsum;
-#ifndef XVIT_DEBUG_TIMES
-  XVIT_REQUIRE(!a->colsum || !use_big_tile(a) || a->split_k > 1, "xvit_gemm: colsum is provided by the small-tile and split-K paths only (use xvit_colsum for large outputs)");
-#endif
   XVIT_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "xvit_gemm: dropout_p must be in [0, 1)");
   p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
   hipStream_t s = (hipStream_t)stream;

@@ -231,16 +231,11 @@ def _linear(x_b, w_s, *, bias=None, residual=None, act=ops.ACT_NONE, aux=None, o
 
 
 def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None, colsum=None, dropout=None):
-    """dx = dy W (+ GELU' / dropout epilogue).  `colsum` (bias gradient of the Linear that produced dx's pre-image):
-    fused into the epilogue on the small / split-K paths, one HBM-bound xvit_colsum pass for large outputs."""
+    """dx = dy W (+ GELU' / dropout epilogue).  `colsum` (bias gradient of the Linear that produced dx's pre-image)
+    is accumulated by the GEMM epilogue itself on every tile path."""
     m, n, k = dy_b.shape[0], w_s.shape[1], w_s.shape[0]
     dx = torch.empty(m, n, dtype=torch.bfloat16, device=dy_b.device)
-    split = _skinny_split(m, n, k)
-    big = m >= 256 and n >= 256 and ((m + 255) // 256) * ((n + 255) // 256) * max(split, 1) > 128    # use_big_tile() of gemm.hip
-    fused = colsum is not None and (split > 1 or not big)
-    ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=colsum if fused else None, dropout=dropout, split_k=split)
-    if colsum is not None and not fused:
-        ops.colsum(dx, out=colsum, accumulate=True)
+    ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=colsum, dropout=dropout, split_k=_skinny_split(m, n, k))
     return dx
 
 

@@ -74,9 +74,9 @@ typedef struct xvit_gemm_args {
   int64_t stride_a, stride_b, stride_c, stride_bias, stride_r, stride_aux; /* per-batch strides */
   void* workspace;         /* caller-owned scratch for split_k > 1 (fp32 partial tiles), else NULL */
   int64_t workspace_bytes;
-  float* colsum;           /* optional fp32 [N]: colsum[n] += sum over rows of the stored C (bias gradient of the producing
-                              Linear); only on the small-tile (M or N < 256) and split-K paths — large outputs use
-                              xvit_colsum, which runs at the same HBM-bound cost; per-batch stride = stride_bias */
+  float* colsum;           /* optional fp32 [N]: colsum[n] += sum over rows of the stored C before its rounding to c_dtype
+                              (bias gradient of the producing Linear; atomic adds, so the caller zeroes it first);
+                              per-batch stride = stride_bias */
   /* nn.Dropout fused after the activation: element (row, col) is kept iff hash(seed, row*N + col) >= p * 2^24
      (the mask xvit_dropout applies to a contiguous [M, N] tensor with the same seed), scaled by 1/(1-p) */
   float dropout_p; int32_t reserved2;

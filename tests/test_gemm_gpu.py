@@ -82,26 +82,21 @@ def test_epilogue_dgelu():
     assert_close(C, (dy @ w) * _dgelu(z), "dgelu")
 
 
-@pytest.mark.parametrize("M,split", [(1026, 1), (3000, 1), (32, 1), (32, 6), (300, 3)])
+@pytest.mark.parametrize("M,split", [(1026, 1), (3000, 1), (21546, 1), (32, 1), (32, 6), (300, 3)])
 def test_epilogue_dgelu_colsum_and_split(M, split):
-    """GELU' epilogue + column sums of the result (bias gradient), direct and through the split-K
-    second pass (small-M GEMMs are split to hide their serial K loop)."""
+    """GELU' epilogue + column sums of the result (bias gradient) on every path: the 256x256 tile kernel (ragged
+    last row tile included), the 128x128 kernel, and the split-K second pass (small-M GEMMs are split to hide
+    their serial K loop)."""
     ops = _ops()
     N, K = 3072, 768
     dy, w, z = rt(randn(M, K, seed=1)), rt(randn(K, N, seed=2, scale=K ** -0.5)), rt(randn(M, N, seed=3))
     C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
-    cs = torch.zeros(N, device=dev())
-    big = M >= 256 and ((M + 255) // 256) * ((N + 255) // 256) * split > 128   # dispatch rule of gemm.hip (use_big_tile)
-    fused = split > 1 or not big          # the big-tile direct path leaves column sums to xvit_colsum
+    cs = torch.full((N,), 0.25, device=dev())          # the kernel accumulates: a non-zero start value must survive
     ops.gemm(ops.NN, dy.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, act=ops.ACT_DGELU, aux=z.to(dev(), torch.bfloat16),
-             colsum=cs if fused else None, split_k=split)
+             colsum=cs, split_k=split)
     ref = (dy @ w) * _dgelu(z)
     assert_close(C, ref, "dgelu")
-    if fused:
-        assert_close(cs, ref.sum(0), "colsum of the epilogue output")
-    else:
-        with pytest.raises(RuntimeError):
-            ops.gemm(ops.NN, dy.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, act=ops.ACT_DGELU, aux=z.to(dev(), torch.bfloat16), colsum=cs)
+    assert_close(cs - 0.25, ref.sum(0), "colsum of the epilogue output")
 
 
 @pytest.mark.parametrize("M,N,K,split", [(32, 768, 3072, 8), (32, 3072, 768, 3), (130, 192, 1024, 4)])
