@@ -160,6 +160,9 @@ template <int QB>
 __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                           int64_t sb, int64_t sn, bf16* __restrict__ o, int64_t osb, int64_t osn,
                                                           float* __restrict__ lse, int H, int N, float scale) {
+#ifdef XVIT_DEBUG_ATTN_TIMES
+  const uint64_t wc_entry = wall_clock64();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;  // [FWD_NST stages][K image | V image]
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
@@ -202,11 +205,20 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
     for (int i = 0; i < 16; ++i) { oacc[qb][0][i] = 0.f; oacc[qb][1][i] = 0.f; }
   }
 
+#ifdef XVIT_DEBUG_ATTN_TIMES
+  const uint64_t wc_loop = wall_clock64();
+  uint64_t tk[5] = {0, 0, 0, 0, 0};
+#define TK(i) if (t == 3) { tk[i] = __builtin_readcyclecounter(); }
+#else
+#define TK(i)
+#endif
   int stage = 0;
   for (int t = 0; t < ntiles; ++t) {
+    TK(0)
     if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t landed; t+1 may be in flight
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();   // every wave's pieces of tile t are in LDS; every wave is done with tile t-1
+    TK(1)
     if (t + FWD_NST - 1 < ntiles) {
       int ns = stage + FWD_NST - 1;
       if (ns >= FWD_NST) ns -= FWD_NST;
@@ -252,6 +264,9 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
           for (int i = 0; i < 16; ++i)
             if (kb * 32 + acc_row(i, h) >= valid) s[qb][kb][i] = -INFINITY;
     }
+#ifdef XVIT_DEBUG_ATTN_TIMES
+    if (t == 3) { asm volatile("s_nop 0" ::"v"(s[0][0][0]), "v"(s[0][1][15])); tk[2] = __builtin_readcyclecounter(); }
+#endif
     // online softmax per query block; the query is this lane's column, split over the two lane halves
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -289,6 +304,9 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
       }
       l_run[qb] += psum;
     }
+#ifdef XVIT_DEBUG_ATTN_TIMES
+    if (t == 3) { asm volatile("s_nop 0" ::"v"(s[0][0][0]), "v"(s[0][1][15])); tk[3] = __builtin_readcyclecounter(); }
+#endif
     // O^T[d][query] += V^T P^T: every V fragment is read once and used by all QB query blocks
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -306,7 +324,19 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
         }
       }
     }
+#ifdef XVIT_DEBUG_ATTN_TIMES
+    if (t == 3) { asm volatile("s_nop 0" ::"v"(oacc[0][0][0]), "v"(oacc[0][1][15])); tk[4] = __builtin_readcyclecounter(); }
+#endif
   }
+#ifdef XVIT_DEBUG_ATTN_TIMES
+  if (lane == 0 && wave_active) {   // borrow the lse buffer: 4 floats per wave = cycles of (wait+barrier, S, softmax, PV) in iteration 3
+    float* dbg = lse + ((((int64_t)b * H + head) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    for (int i = 0; i < 4; ++i) dbg[i] = (float)(tk[i + 1] - tk[i]);
+    const uint64_t wc_end = wall_clock64();
+    dbg[4] = (float)(wc_entry & 0xFFFFFF); dbg[5] = (float)(wc_loop - wc_entry); dbg[6] = (float)(wc_end - wc_loop); dbg[7] = 0.f;   // 100 MHz ticks
+  }
+  return;
+#endif
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
@@ -448,6 +478,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   const int64_t stat0 = ((int64_t)b * H + head) * N;
   const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
 
+#ifdef XVIT_DEBUG_ATTN_TIMES
+  const uint64_t wc_entry = wall_clock64();
+  uint64_t tk[4] = {0, 0, 0, 0};
+#endif
   TileLoader lq, ldo;
   lq.init(q + off, sn, N, wave, lane);
   ldo.init(d_o + ooff, osn, N, wave, lane);
@@ -481,10 +515,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
 
+#ifdef XVIT_DEBUG_ATTN_TIMES
+  const uint64_t wc_loop = wall_clock64();
+#endif
   int stage = 0;
   for (int t = 0; t < ntiles; ++t) {
+#ifdef XVIT_DEBUG_ATTN_TIMES
+    if (t == 3) tk[0] = __builtin_readcyclecounter();
+    if (t == 4) tk[2] = __builtin_readcyclecounter();
+#endif
     ring_wait<BWD_NST, 5>(t, ntiles);
     __builtin_amdgcn_s_barrier();   // every wave's pieces of tile t are in LDS; every wave is done with tile t-1
+#ifdef XVIT_DEBUG_ATTN_TIMES
+    if (t == 3) tk[1] = __builtin_readcyclecounter();
+#endif
     if (t + BWD_NST - 1 < ntiles) {
       int ns = stage + BWD_NST - 1;
       if (ns >= BWD_NST) ns -= BWD_NST;
@@ -532,6 +576,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
       }
     }
   }
+#ifdef XVIT_DEBUG_ATTN_TIMES
+  if (lane == 0 && wave_active) {   // borrow dk (bf16 [*, sn] rows): 8 floats per wave written at the start of this block's first dK row... use delta workspace instead
+    float* dbg = const_cast<float*>(delta) + ((((int64_t)b * H + head) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    asm volatile("s_nop 0" ::"v"(dkacc[0][0]), "v"(dkacc[1][15]), "v"(dvacc[0][0]), "v"(dvacc[1][15]));
+    const uint64_t wc_end = wall_clock64();
+    dbg[0] = (float)(tk[1] - tk[0]); dbg[1] = (float)(tk[2] - tk[1]); dbg[2] = 0.f; dbg[3] = 0.f;
+    dbg[4] = (float)(wc_entry & 0xFFFFFF); dbg[5] = (float)(wc_loop - wc_entry); dbg[6] = (float)(wc_end - wc_loop); dbg[7] = 0.f;
+  }
+  asm volatile("" ::"v"(dkacc[0][0]), "v"(dkacc[1][15]), "v"(dvacc[0][0]), "v"(dvacc[1][15]));   // keep the accumulations alive
+  return;
+#endif
   const int krow = k0 + (lane & 31);
   const bool valid = krow < N;
   store_lane_rows(dkacc, scale, dk + off, sn, krow, valid, lane);
