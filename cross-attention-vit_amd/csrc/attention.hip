@@ -111,6 +111,24 @@ __device__ __forceinline__ void settle(bf16x8 (&f)[4]) {
   }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin in dispatch order (x fastest), each XCD with its own L2.
+// Remap the linear id so that a contiguous range of LOGICAL ids runs on one XCD: the query (or key) blocks of
+// one (batch, head) then share an L2 and its K/V (Q/dO) tiles are fetched from HBM once, not once per XCD
+// (measured before the remap: 350-390 MB fetched per launch against ~100 MB of q/k/v).
+struct BlockCoord { int x, head, b; };
+__device__ __forceinline__ BlockCoord xcd_block_coord() {
+  const int nx = gridDim.x, nh = gridDim.y, total = nx * nh * gridDim.z;
+  const int lin = blockIdx.x + nx * (blockIdx.y + nh * blockIdx.z);
+  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  BlockCoord c;
+  c.x = logical % nx;
+  const int rest = logical / nx;
+  c.head = rest % nh;
+  c.b = rest / nh;
+  return c;
+}
+
 // counted wait on the vector-memory counter (the LDS-DMA ring: "at most N loads still in flight")
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -166,8 +184,9 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;  // [FWD_NST stages][K image | V image]
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * (128 * QB) + wave * (32 * QB);
+  const BlockCoord bc = xcd_block_coord();
+  const int b = bc.b, head = bc.head;
+  const int q0 = bc.x * (128 * QB) + wave * (32 * QB);
   const int64_t off = (int64_t)b * sb + head * DH;
   const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
 
@@ -330,7 +349,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
   }
 #ifdef XVIT_DEBUG_ATTN_TIMES
   if (lane == 0 && wave_active) {   // borrow the lse buffer: 4 floats per wave = cycles of (wait+barrier, S, softmax, PV) in iteration 3
-    float* dbg = lse + ((((int64_t)b * H + head) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    float* dbg = lse + ((((int64_t)b * H + head) * gridDim.x + bc.x) * 4 + wave) * 8;
     for (int i = 0; i < 4; ++i) dbg[i] = (float)(tk[i + 1] - tk[i]);
     const uint64_t wc_end = wall_clock64();
     dbg[4] = (float)(wc_entry & 0xFFFFFF); dbg[5] = (float)(wc_loop - wc_entry); dbg[6] = (float)(wc_end - wc_loop); dbg[7] = 0.f;   // 100 MHz ticks
@@ -382,8 +401,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const BlockCoord bc = xcd_block_coord();
+  const int b = bc.b, head = bc.head;
+  const int q0 = bc.x * 128 + wave * 32;
   const int64_t off = (int64_t)b * sb + head * DH;
   const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
 
@@ -471,8 +491,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
-  const int b = blockIdx.z, head = blockIdx.y;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const BlockCoord bc = xcd_block_coord();
+  const int b = bc.b, head = bc.head;
+  const int k0 = bc.x * 128 + wave * 32;
   const int64_t off = (int64_t)b * sb + head * DH;
   const int64_t ooff = (int64_t)b * osb + head * DH;
   const int64_t stat0 = ((int64_t)b * H + head) * N;
@@ -578,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   }
 #ifdef XVIT_DEBUG_ATTN_TIMES
   if (lane == 0 && wave_active) {   // borrow dk (bf16 [*, sn] rows): 8 floats per wave written at the start of this block's first dK row... use delta workspace instead
-    float* dbg = const_cast<float*>(delta) + ((((int64_t)b * H + head) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+    float* dbg = const_cast<float*>(delta) + ((((int64_t)b * H + head) * gridDim.x + bc.x) * 4 + wave) * 8;
     asm volatile("s_nop 0" ::"v"(dkacc[0][0]), "v"(dkacc[1][15]), "v"(dvacc[0][0]), "v"(dvacc[1][15]));
     const uint64_t wc_end = wall_clock64();
     dbg[0] = (float)(tk[1] - tk[0]); dbg[1] = (float)(tk[2] - tk[1]); dbg[2] = 0.f; dbg[3] = 0.f;
