@@ -515,12 +515,18 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;   // 2 x 4 waves
 
-  const int nblk = gridDim.x, bid = blockIdx.x;
-  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-  const int tm = logical / p.ntn, tn = logical - tm * p.ntn;
+  // XCD-aware bijective remap over the whole (tile, batch x split) grid: workgroups are dealt to the 8 XCDs
+  // round-robin in dispatch order (x fastest, then z), so logical ids [xcd * total/8, (xcd+1) * total/8) run on
+  // one XCD.  Consecutive logical ids walk the tiles of ONE K-split (sharing its A and B panels through that
+  // XCD's L2) before moving to the next split; with the tile index alone (36 tiles, not a multiple of 8) the
+  // split-K wgrads fetched 2.3x their algorithmic bytes.
+  const int nblk = gridDim.x, total = nblk * gridDim.z, lin = blockIdx.x + nblk * blockIdx.z;
+  const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
+  const int zz = logical / nblk, tile = logical - zz * nblk;
+  const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
   const int m0 = tm * TBM, n0 = tn * TBN;
-  const int batch = blockIdx.z / p.split_k, split = blockIdx.z - batch * p.split_k;
+  const int batch = zz / p.split_k, split = zz - batch * p.split_k;
   const int k_begin = split * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin + BK - 1) / BK;   // may be 0 for a trailing split: still writes its (zero) slab
