@@ -171,38 +171,47 @@ class MultiScaleBlock(nn.Module):
                 cls._streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
         return cls._streams[key]
 
-    def _branches(self, x):
-        """The M modality branches are independent until fusion (separate weights, :122): run each on
-        its own HIP stream so their kernels interleave on the chip (one GEMM's tail round / HBM-bound
-        epilogue overlaps the other's MFMA phase).  autograd replays backward on the same streams."""
-        if len(x) < 2 or not x[0].is_cuda or os.environ.get("XVIT_STREAMS", "1") == "0":
-            return [block(x_) for x_, block in zip(x, self.blocks)]
-        cur = torch.cuda.current_stream(x[0].device)
+    def _parallel(self, thunks, tensors, kind="branches"):
+        """Run independent pieces of work (one per modality) each on its own HIP stream so their kernels interleave
+        on the chip (one GEMM's tail round / HBM-bound epilogue overlaps the other's MFMA phase, and the strings of
+        tiny CLS-row launches of the two fusions overlap each other).  `tensors` are the inputs the side streams
+        read.  autograd replays backward on the same streams."""
+        mode = os.environ.get("XVIT_STREAMS", "1")     # "1": branches and fusions, "branches": branches only, "0": one stream
+        if len(thunks) < 2 or not tensors[0].is_cuda or mode == "0" or (mode == "branches" and kind != "branches"):
+            return [f() for f in thunks]
+        dev = tensors[0].device
+        cur = torch.cuda.current_stream(dev)
+        streams = self._branch_streams(dev, len(thunks))
         outs = []
-        for x_, block, st in zip(x, self.blocks, self._branch_streams(x[0].device, len(x))):
+        for f, st in zip(thunks, streams):
             st.wait_stream(cur)
-            x_.record_stream(st)
+            for t in tensors:
+                t.record_stream(st)
             with torch.cuda.stream(st):
-                outs.append(block(x_))
-        for y, st in zip(outs, self._branch_streams(x[0].device, len(x))):
+                outs.append(f())
+        for y, st in zip(outs, streams):
             cur.wait_stream(st)
             y.record_stream(cur)
         return outs
 
+    def _branches(self, x):
+        """The M modality branches are independent until fusion (separate weights, :122)."""
+        return self._parallel([(lambda x_=x_, block=block: block(x_)) for x_, block in zip(x, self.blocks)], list(x))
+
     def forward(self, x):
         attn = self._branches(x)
-        outs = []
+        thunks = []
         cross_count = 0
         for i in range(len(self.blocks)):
             if str(i) in self.attn_order:
                 j = int(self.attn_order[str(i)])
                 blk = self.fusion[cross_count]
                 # cls of i + patch tokens of j -> new cls, re-attached to i's own patch tokens (:140-142)
-                outs.append(XF.CrossFusionFn.apply(attn[i], attn[j], *_fusion_args(blk), True, _p(blk, blk.attn.fn.attn_drop)))
+                thunks.append(lambda i=i, j=j, blk=blk: XF.CrossFusionFn.apply(attn[i], attn[j], *_fusion_args(blk), True, _p(blk, blk.attn.fn.attn_drop)))
                 cross_count += 1
             else:
-                outs.append(attn[i])
-        return outs
+                thunks.append(lambda i=i: attn[i])
+        return self._parallel(thunks, list(attn), kind="fusion")   # the fusions only read the branch outputs: independent of each other
 
 
 class ModelCross(_Base):

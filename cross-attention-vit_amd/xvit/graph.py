@@ -11,7 +11,8 @@ graph's private pool.
     optimizer.step()                                         # outside the graph
 
 Restrictions: static shapes; dropout must be inactive (masks are seeded on the host per call, a replay would repeat
-them); the modality branches are captured on one stream.
+them).  The per-modality self-attention branches fork from and join back into the capture stream, so the graph
+keeps them as parallel paths (XVIT_GRAPH_STREAMS=0 captures everything on one stream instead).
 """
 from __future__ import annotations
 
@@ -34,7 +35,9 @@ class GraphedStep:
         self.img = img.clone()
         self.labels = labels.clone()
         self._prev_streams = os.environ.get("XVIT_STREAMS")
-        os.environ["XVIT_STREAMS"] = "0"
+        # fork only the self-attention branches inside the capture: with the fusions forked as well, torch 2.10 / ROCm 7.0
+        # segfaults in capture_end (eager mode runs that pattern fine).  XVIT_GRAPH_STREAMS=0 captures on one stream.
+        os.environ["XVIT_STREAMS"] = "0" if os.environ.get("XVIT_GRAPH_STREAMS", "1") == "0" else "branches"
         side = torch.cuda.Stream(device=img.device)
         side.wait_stream(torch.cuda.current_stream(img.device))
         with torch.cuda.stream(side):
