@@ -36,7 +36,7 @@ import torch.distributed as dist  # noqa: E402
 # HBM bytes per launch of the dominant kernel family, from the rocprofv3 --pmc passes committed under profiles/
 # (FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE), averaged over the family's launches
 # of one step at the default batch.  Filled in from profiles/r01_pmc_traffic.md; None = not measured.
-TRAFFIC = {"gemm_big_nt": 2.87e8, "gemm_big_nn": 2.18e8, "gemm_big_tn+splitk": 3.10e8}   # profiles/r01_b_summary.md
+TRAFFIC = {"gemm_big_nt": 8.41e8, "gemm_big_nn": 6.66e8, "gemm_big_tn+splitk": 5.95e8}   # bytes per launch at the default batch (126): profiles/r01_c_summary.md
 
 MFMA_PEAK_TF = 2516.0   # bf16 dense, MI355X_MICROARCH.md: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0   # HBM3E spec
@@ -115,7 +115,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=42, help="per-GPU batch of volume pairs (42*513 rows = 85 row tiles of 256: 85*3 = 255 tiles per d-wide GEMM on 256 CUs)")
+    ap.add_argument("--batch", type=int, default=126, help="per-GPU batch of volume pairs.  Throughput rises with batch until ~126 (42: 2.79 M, 84: 2.99 M, 126: 3.03 M, "
+                    "252: 3.06 M tokens/s; 18.7 GB of the 288 GB HBM at 126); 126*513 rows = 253 row tiles of 256 -> 759 / 1518 / 2277 / 3036 tiles per GEMM "
+                    "= 2.96 .. 11.9 rounds of 256 CUs, so the last round of every launch is nearly full")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--detail", action="store_true", help="per-shape GEMM table on stderr (diagnostic)")
@@ -218,6 +220,7 @@ def main():
         "model_tflops_per_gpu": round(both_f * B / (dt / args.steps) / 1e12, 1),
         "mfma_frac_of_peak_step": round(both_f * B / (dt / args.steps) / 1e12 / MFMA_PEAK_TF, 4),
         "loss": round(loss_val, 5),
+        "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
     }
 
     # ---- per-kernel pricing with HIP events on the launch stream (rank 0) --------------------

@@ -16,10 +16,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def one(pattern):
-    hits = sorted(glob.glob(pattern, recursive=True))
+    hits = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
     if not hits:
         raise SystemExit(f"nothing matches {pattern}")
-    return hits[0]
+    return hits[-1]          # the newest: gpurun merges every session into the same local directory
 
 
 def short(name):
