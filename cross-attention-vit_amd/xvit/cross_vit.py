@@ -257,7 +257,7 @@ class ModelCross(_Base):
             raise ValueError(f"expected {self.num_modalities} modalities, got {img.shape[1]}")
         tokens = XF.PatchEmbedFn.apply(img, self.patch_to_embedding.weight, self.patch_to_embedding.bias,
                                        self.cls_token, self.pos_embedding, self.patch_size, _p(self, self.dropout))
-        x = self.transformer([tokens[m] for m in range(self.num_modalities)])
+        x = self.transformer(list(tokens))
         per_mod = [XF.HeadFn.apply(x[m], self.norm[m].weight, self.norm[m].bias, self.mlp_head[m][0].weight, self.mlp_head[m][0].bias,
                                    self.mlp_head[m][3].weight, self.mlp_head[m][3].bias, self.norm[m].eps, _p(self, self.mlp_head[m][2]))
                    for m in range(self.num_modalities)]

@@ -491,22 +491,35 @@ class PatchEmbedFn(Function):
             ops.dropout(x, p, seed, out=x)
         ctx.meta = (M, Bn, N, d, p, seed)
         ctx.save_for_backward(patches)
-        return x.reshape(Bn, N, d) if concat else x.reshape(M, Bn, N, d)
+        if concat:
+            return x.reshape(Bn, N, d)
+        # one output per modality (views of one buffer): slicing a stacked [M, B, N, d] output in the caller would cost
+        # autograd two full-size zero fills, two slice copies and a full-size add per step (select_backward)
+        return tuple(x.reshape(M, Bn, N, d).unbind(0))
 
     @staticmethod
-    def backward(ctx, dx):
+    def backward(ctx, *dxs):
         M, Bn, N, d, p, seed = ctx.meta
         (patches,) = ctx.saved_tensors
-        dx2 = _f32c(dx).reshape(M * Bn * N, d)
-        if p > 0.0:
-            dx2 = ops.dropout(dx2, p, seed)
-        dxb = ops.cast_bf16(dx2)
+        dev = patches.device
+        dpos = torch.zeros(N, d, dtype=torch.float32, device=dev)
+        dcls = torch.zeros(d, dtype=torch.float32, device=dev)
+        if len(dxs) == 1 or p > 0.0:         # single sequence (ModelVIT), or dropout (its mask is keyed by the index in the stacked tensor)
+            dx = dxs[0] if len(dxs) == 1 else torch.stack([_f32c(g) for g in dxs])
+            dx2 = _f32c(dx).reshape(M * Bn * N, d)
+            if p > 0.0:
+                dx2 = ops.dropout(dx2, p, seed)
+            dxb = ops.cast_bf16(dx2)
+            ops.embed_bwd(dx2, dpos, dcls, M * Bn, N, d)
+        else:                                # per-modality gradients: cast each into its slice of ONE bf16 operand, no stacking copy
+            dxb = torch.empty(M * Bn * N, d, dtype=torch.bfloat16, device=dev)
+            for m, g in enumerate(dxs):
+                g2 = _f32c(g).reshape(Bn * N, d)
+                ops.cast_bf16(g2, dxb[m * Bn * N:(m + 1) * Bn * N])
+                ops.embed_bwd(g2, dpos, dcls, Bn, N, d)      # accumulates into dpos / dcls
         dW = _wgrad(dxb, patches)            # the zero CLS rows of `patches` drop the CLS-row gradients
-        dpos = torch.zeros(N, d, dtype=torch.float32, device=dx.device)
-        dcls = torch.zeros(d, dtype=torch.float32, device=dx.device)
-        ops.embed_bwd(dx2, dpos, dcls, M * Bn, N, d)
         db = ops.colsum(dpos[1:])            # bias reaches the P patch rows of every sample
-        _join_wgrads(dx.device)
+        _join_wgrads(dev)
         return None, dW, db, dcls.reshape(1, 1, d), dpos.reshape(1, N, d), None, None, None
 
 
