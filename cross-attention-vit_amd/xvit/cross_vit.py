@@ -198,7 +198,9 @@ class MultiScaleBlock(nn.Module):
         """The M modality branches are independent until fusion (separate weights, :122)."""
         return self._parallel([(lambda x_=x_, block=block: block(x_)) for x_, block in zip(x, self.blocks)], list(x))
 
-    def forward(self, x):
+    def forward(self, x, cls_only=False):
+        """cls_only (used by ModelCross for its last block, whose outputs are read through their CLS rows only): the
+        fusions return [B, 1, d] instead of re-attaching the new CLS token to a copy of the patch tokens."""
         attn = self._branches(x)
         thunks = []
         cross_count = 0
@@ -207,7 +209,7 @@ class MultiScaleBlock(nn.Module):
                 j = int(self.attn_order[str(i)])
                 blk = self.fusion[cross_count]
                 # cls of i + patch tokens of j -> new cls, re-attached to i's own patch tokens (:140-142)
-                thunks.append(lambda i=i, j=j, blk=blk: XF.CrossFusionFn.apply(attn[i], attn[j], *_fusion_args(blk), True, _p(blk, blk.attn.fn.attn_drop)))
+                thunks.append(lambda i=i, j=j, blk=blk: XF.CrossFusionFn.apply(attn[i], attn[j], *_fusion_args(blk), not cls_only, _p(blk, blk.attn.fn.attn_drop)))
                 cross_count += 1
             else:
                 thunks.append(lambda i=i: attn[i])
@@ -257,7 +259,11 @@ class ModelCross(_Base):
             raise ValueError(f"expected {self.num_modalities} modalities, got {img.shape[1]}")
         tokens = XF.PatchEmbedFn.apply(img, self.patch_to_embedding.weight, self.patch_to_embedding.bias,
                                        self.cls_token, self.pos_embedding, self.patch_size, _p(self, self.dropout))
-        x = self.transformer(list(tokens))
+        x = list(tokens)
+        for k, blk in enumerate(self.transformer):                       # nn.Sequential of MultiScaleBlocks (model_cross.py:171)
+            last = k == len(self.transformer) - 1                        # only x[m][:, 0] of the last block is read below (model_cross.py:203) ...
+            observed = bool(blk._forward_hooks) or bool(self.transformer._forward_hooks)   # ... unless a hook wants the reference's full output
+            x = blk(x, cls_only=last and not observed)
         per_mod = [XF.HeadFn.apply(x[m], self.norm[m].weight, self.norm[m].bias, self.mlp_head[m][0].weight, self.mlp_head[m][0].bias,
                                    self.mlp_head[m][3].weight, self.mlp_head[m][3].bias, self.norm[m].eps, _p(self, self.mlp_head[m][2]))
                    for m in range(self.num_modalities)]

@@ -184,6 +184,35 @@ def test_model_cross_vs_bf16_emulating_oracle(name, batch):
     assert abs(float(loss) - float(ref_loss)) < 2e-3
 
 
+def test_unobserved_last_block_cls_only_path_matches_full_path():
+    """ModelCross runs its last MultiScaleBlock CLS-only when nothing observes the block's output (the heads read
+    x[m][:, 0] only, model_cross.py:203); with a forward hook it produces the reference's full token tensors.  Both
+    paths must give the same logits, loss and parameter gradients."""
+    import xvit
+    cfg = R.make_config("tiny")
+    img, labels = R.make_inputs(cfg, 3, seed=5)
+    img, labels = img.to(dev()), labels.to(dev())
+    model = xvit.ModelCross(cfg).to(dev())
+    model.train()
+
+    def run(observed):
+        shapes = []
+        hooks = [model.transformer[-1].register_forward_hook(lambda m, i, o: shapes.append([tuple(t.shape) for t in o]))] if observed else []
+        model.zero_grad()
+        logits, loss = model(img, labels)
+        loss.backward()
+        for h in hooks:
+            h.remove()
+        return logits.detach().clone(), float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters()}, shapes
+
+    l_full, loss_full, g_full, shapes = run(True)
+    assert all(s[1] == cfg.img_size[0] // cfg.patch_size[0] * (cfg.img_size[1] // cfg.patch_size[1]) * (cfg.img_size[2] // cfg.patch_size[2]) + 1 for s in shapes[0])
+    l_cls, loss_cls, g_cls, _ = run(False)
+    assert torch.equal(l_full, l_cls) and loss_full == loss_cls      # the CLS rows go through the very same kernels
+    for k in g_full:
+        assert rel(g_cls[k], g_full[k]) < 1e-5 or float(g_full[k].abs().max()) < 1e-6, k
+
+
 def test_accumulates_like_autograd_and_fails_loudly_off_gpu():
     import xvit
     cfg = R.make_config("tiny")
