@@ -108,3 +108,33 @@ def test_layernorm_output_statistics_at_full_size():
     y, mean, rstd = ops.layernorm_fwd(x, torch.ones(d, device=dev()), torch.zeros(d, device=dev()), 1e-5)
     yf = y.float()
     assert float(yf.mean(dim=1).abs().max()) < 5e-3 and float((yf.var(dim=1, unbiased=False) - 1).abs().max()) < 2e-2
+
+
+def test_workgroups_are_dealt_round_robin_to_the_xcds_and_cu_masks_restrict_streams():
+    """The tile / block remaps in gemm.hip and attention.hip assume that workgroup i of a launch runs on XCD i % 8
+    (each XCD with its own L2).  xvit_cu_trace records where every workgroup actually ran; a CU-masked stream
+    (xvit/cu_mask.py) must confine a launch to its share of the CUs on every XCD."""
+    from xvit import _lib, cu_mask
+    n = 2048
+    out = torch.zeros(2 * n, dtype=torch.int32, device=dev())
+    st = torch.cuda.current_stream()
+    _lib.check(_lib.load().xvit_cu_trace(out.data_ptr(), n, 20, st.cuda_stream), "xvit_cu_trace")
+    torch.cuda.synchronize()
+    xcc = (out.view(n, 2)[:, 0] & 0xF).cpu()
+    n_xcd = int(xcc.max()) + 1
+    assert n_xcd == 8
+    assert torch.equal(xcc[:64], torch.arange(64) % n_xcd)          # dispatch order -> XCD, round-robin
+
+    def places(stream):
+        o = torch.zeros(2 * n, dtype=torch.int32, device=dev())
+        with torch.cuda.stream(stream):
+            _lib.check(_lib.load().xvit_cu_trace(o.data_ptr(), n, 30, stream.cuda_stream), "xvit_cu_trace")
+        stream.synchronize()
+        o = o.view(n, 2).cpu()
+        return {(int(x) & 0xF, (int(h) >> 8) & 0xFF) for x, h in o.tolist()}     # (XCD, se/sh/cu bits of HW_ID)
+
+    n_cu = torch.cuda.get_device_properties(dev()).multi_processor_count
+    assert len(places(torch.cuda.Stream(dev()))) == n_cu
+    halves = [places(cu_mask.masked_stream(dev(), bits)) for bits in cu_mask.split_masks(n_cu, 2)]
+    assert len(halves[0]) == n_cu // 2 and len(halves[1]) == n_cu // 2 and not (halves[0] & halves[1])
+    assert {x for x, _ in halves[0]} == set(range(n_xcd))            # a contiguous bit range = the same CU slice on every XCD
