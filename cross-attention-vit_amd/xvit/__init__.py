@@ -11,3 +11,4 @@ from .model import Block, Encoder, Mlp, MultiHeadAttention  # noqa: F401
 from .modelv3 import ModelVIT, Transformer  # noqa: F401
 from .model_cross import (Attention, CrossAttention, CrossAttentionBlock, FeedForward, ModelCross,  # noqa: F401
                           MultiScaleBlock, PreNorm, SelfAttentionBlock)
+from .metrics import BinaryEpochMetrics  # noqa: F401

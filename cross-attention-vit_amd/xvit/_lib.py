@@ -41,6 +41,7 @@ SIGNATURES = {
     "xvit_colsum": [vp, i32, i64, vp, i32, i32, i32, vp],
     "xvit_dropout": [vp, vp, i32, i64, f32, u64, vp],
     "xvit_cu_trace": [vp, i32, i32, vp],
+    "xvit_binary_metrics_step": [vp, i64, vp, i32, i32, vp, vp],
     "xvit_mean_ce": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp],
     "xvit_resize_pad_crop_i16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "xvit_adam_step": [vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp],

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import functional as XF
+from .metrics import EpochStatsMixin
 
 try:  # the reference derives ModelCross from lightning.LightningModule (model_cross.py:152)
     import lightning as _L  # type: ignore
@@ -216,7 +217,7 @@ class MultiScaleBlock(nn.Module):
         return self._parallel(thunks, list(attn), kind="fusion")   # the fusions only read the branch outputs: independent of each other
 
 
-class ModelCross(_Base):
+class ModelCross(EpochStatsMixin, _Base):
     """model_cross.py:152-308.  forward(img [B, M, 1, D, H, W], labels [B]) -> (logits, loss)."""
 
     def __init__(self, config):
@@ -296,12 +297,14 @@ class ModelCross(_Base):
         x, labels = batch
         logits, loss = self(x, labels)
         self.log('train_loss', loss, on_epoch=True, on_step=False, sync_dist=True)
+        self.log_stats('train', logits, labels)
         return loss
 
     def validation_step(self, batch, batch_idx):
         x, labels = batch
         logits, loss = self(x, labels)
         self.log('val_loss', loss, on_epoch=True, on_step=False, sync_dist=True)
+        self.log_stats('val', logits, labels)
 
     def configure_optimizers(self):
         optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)

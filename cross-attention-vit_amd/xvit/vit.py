@@ -10,6 +10,7 @@ import torch.nn as nn
 
 from . import functional as XF
 from .cross_vit import Attention, FeedForward, PreNorm, _Base, _lin, _p
+from .metrics import EpochStatsMixin
 
 
 class _NoDrop(nn.Module):
@@ -39,7 +40,7 @@ class Transformer(nn.Module):
         return x
 
 
-class ModelVIT(_Base):
+class ModelVIT(EpochStatsMixin, _Base):
     """modelv3.py:90-147.  forward(img [B, M, 1, D, H, W], labels [B]) -> (logits, loss)."""
 
     def __init__(self, config):
@@ -96,12 +97,14 @@ class ModelVIT(_Base):
         x, labels = batch
         logits, loss = self(x, labels)
         self.log('train_loss', loss, on_epoch=True, on_step=False, sync_dist=True)
+        self.log_stats('train', logits, labels)
         return loss
 
     def validation_step(self, batch, batch_idx):
         x, labels = batch
         logits, loss = self(x, labels)
         self.log('val_loss', loss, on_epoch=True, on_step=False, sync_dist=True)
+        self.log_stats('val', logits, labels)
 
     def configure_optimizers(self):
         optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, weight_decay=self.weight_decay)

@@ -172,6 +172,16 @@ int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, i
  * y = x * keep / (1-p).  In-place allowed.  dtype XVIT_BF16 | XVIT_F32. */
 int xvit_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, xvit_stream_t stream);
 
+/* Per-step classification statistics kept on the device (replaces log_stats -> compute_metrics, model_cross.py:243-255 /
+   utils.py:18-62: six torchmetrics objects, six .item() host syncs and an AUROC per step).  logits fp32 [B, C = 2] (row stride
+   ld), labels int64 [B].  pred = argmax; the step's accuracy, precision, recall, specificity, F1, NPV (0 for an empty
+   denominator) and exact AUROC of softmax(logits)[:, 1] (0 if a class is absent) are folded into
+   state[XVIT_METRIC_STATE] (fp64, caller-zeroed at the start of an epoch):
+     [0..3] pooled tn, fp, fn, tp   [4] samples   [5] steps   [6..12] sum of batch_size * {acc, prec, rec, spec, f1, npv, auroc}
+   so state[6+k] / state[4] is the batch-size-weighted epoch mean Lightning logs for on_epoch=True.  B <= 8192. */
+#define XVIT_METRIC_STATE 16
+int xvit_binary_metrics_step(const float* logits, int64_t ld, const int64_t* labels, int B, int C, double* state, xvit_stream_t stream);
+
 /* Diagnostic (no reference counterpart): out[2*b] = XCC (XCD) id and out[2*b+1] = HW_ID register of the CU
    that ran workgroup b of an `nblocks`-block launch on `stream`; every block lingers `linger_us` so the
    launch spreads over all CUs the stream may use.  Maps CU-mask bits of a masked stream to XCDs. */

@@ -473,3 +473,50 @@ def encoder_forward(sd, x, H, layers):
     for l in range(layers):
         x = encoder_block(sd, f"layers.{l}", x, H)
     return layer_norm(x, sd["encoder_norm.weight"], sd["encoder_norm.bias"], 1e-6)
+
+
+# ------------------------------------------------------------------------------------------
+# §8(f)-4: the per-step statistics of log_stats (model_cross.py:243-255 -> utils.py:18-62)
+# ------------------------------------------------------------------------------------------
+METRIC_KEYS = ("acc", "prec", "rec", "spec", "f1", "npv", "auc_roc")
+
+
+def binary_step_metrics(logits: torch.Tensor, labels: torch.Tensor) -> dict:
+    """One step of the reference's log_stats, restated without torchmetrics (absent from this image, so parity with
+    torchmetrics itself is unpinned; tests/test_oracle.py pins every value against scikit-learn instead).
+      pred = argmax(logits, 1)                                   model_cross.py:244
+      accuracy, precision, recall, specificity, F1 of (pred, labels) with 0 for an empty denominator
+        (torchmetrics' _safe_divide)                             utils.py:33-46
+      NPV = tn / (tn + fn) if tn + fn > 0 else 0                 utils.py:49-53
+      AUROC of softmax(logits)[:, 1] — the exact ROC area, i.e. P(p_pos > p_neg) + 0.5 P(p_pos == p_neg); 0 when one
+        class is absent from the batch (torchmetrics returns zero there)      model_cross.py:253-254
+    Returns the seven values plus the confusion counts (tn, fp, fn, tp)."""
+    logits = logits.detach().float().cpu()
+    y = (labels.detach().cpu() != 0)
+    pred = logits[:, 1] > logits[:, 0]                       # ties -> class 0 (first maximum)
+    tp = int((pred & y).sum()); tn = int((~pred & ~y).sum()); fp = int((pred & ~y).sum()); fn = int((~pred & y).sum())
+    div = lambda a, b: a / b if b > 0 else 0.0               # noqa: E731
+    prob = torch.softmax(logits, dim=1)[:, 1]
+    pos, neg = prob[y], prob[~y]
+    if len(pos) == 0 or len(neg) == 0:
+        auc = 0.0
+    else:
+        gt = (pos[:, None] > neg[None, :]).sum().item()
+        eq = (pos[:, None] == neg[None, :]).sum().item()
+        auc = (gt + 0.5 * eq) / (len(pos) * len(neg))
+    return {"acc": div(tp + tn, tp + tn + fp + fn), "prec": div(tp, tp + fp), "rec": div(tp, tp + fn), "spec": div(tn, tn + fp),
+            "f1": div(2 * tp, 2 * tp + fp + fn), "npv": div(tn, tn + fn), "auc_roc": auc, "counts": (tn, fp, fn, tp)}
+
+
+def epoch_metrics(steps) -> dict:
+    """What Lightning logs for `self.log(value, on_epoch=True, on_step=False)` over an epoch: the batch-size-weighted
+    mean of the per-step values.  steps: iterable of (logits, labels)."""
+    tot = {k: 0.0 for k in METRIC_KEYS}
+    n = 0
+    for logits, labels in steps:
+        m = binary_step_metrics(logits, labels)
+        b = int(labels.shape[0])
+        for k in METRIC_KEYS:
+            tot[k] += m[k] * b
+        n += b
+    return {k: v / max(n, 1) for k, v in tot.items()}

@@ -69,3 +69,49 @@ def test_bucketed_reducer_world2(tmp_path):
         assert torch.allclose(g0[k], p.grad, rtol=1e-5, atol=1e-7), k          # == global-batch gradient
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k                                   # replicas stay in lock-step
+
+
+# ---- sync_dist of the on-device epoch statistics (xvit/metrics.py): the state vectors are summed over the ranks -----
+def _oracle_state(steps):
+    """the 16-double state xvit_binary_metrics_step would have accumulated, from the oracle (no GPU here)"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu as R
+    st = torch.zeros(16, dtype=torch.float64)
+    for logits, labels in steps:
+        m = R.binary_step_metrics(logits, labels)
+        b = float(len(labels))
+        st[0:4] += torch.tensor(m["counts"], dtype=torch.float64)
+        st[4] += b
+        st[5] += 1
+        st[6:13] += b * torch.tensor([m[k] for k in R.METRIC_KEYS], dtype=torch.float64)
+    return st
+
+
+def _rank_steps(rank):
+    g = torch.Generator().manual_seed(50 + rank)
+    return [(torch.randn(b, 2, generator=g), torch.randint(0, 2, (b,), generator=g)) for b in ((9, 9, 4) if rank == 0 else (9, 9, 9, 2))]
+
+
+def _metrics_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "cross-attention-vit_amd"))
+    from xvit.metrics import BinaryEpochMetrics
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    acc = BinaryEpochMetrics("cpu")
+    acc.state.copy_(_oracle_state(_rank_steps(rank)))
+    torch.save((acc.compute("val"), acc.compute("val", sync_dist=False)), os.path.join(out_dir, f"m{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_epoch_statistics_sync_dist_world2(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu as R
+    port = _free_port()
+    mp.spawn(_metrics_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    (all0, loc0), (all1, loc1) = torch.load(tmp_path / "m0.pt"), torch.load(tmp_path / "m1.pt")
+    assert all0 == all1                                           # every rank logs the same epoch values
+    ref = R.epoch_metrics(_rank_steps(0) + _rank_steps(1))        # = the weighted mean over the global batch stream
+    for k in R.METRIC_KEYS:
+        assert abs(all0[f"val_{k}"] - ref[k]) < 1e-12, k
+    assert all0["val_confusion"]["samples"] == 22 + 29 and all0["val_confusion"]["steps"] == 7
+    assert loc0["val_confusion"]["samples"] == 22 and loc1["val_confusion"]["samples"] == 29

@@ -131,3 +131,39 @@ def test_resize_with_pad_or_crop_rule():
     big = torch.zeros(240, 240, 155, dtype=torch.int16); big[56, 56, 13] = 7; big[183, 183, 140] = 9
     out = R.resize_with_pad_or_crop(big, (128, 128, 128), -1)
     assert out[0, 0, 0] == 7 and out[127, 127, 127] == 9
+
+
+def test_step_metrics_restatement_vs_scikit_learn():
+    """oracle.binary_step_metrics (log_stats, model_cross.py:243-255) against scikit-learn's definitions of the same
+    quantities (torchmetrics is not installed here): random batches, ties, single-class batches."""
+    import numpy as np
+    from sklearn import metrics as skm
+    g = torch.Generator().manual_seed(3)
+    cases = []
+    for B in (1, 2, 7, 64, 126):
+        logits = torch.randn(B, 2, generator=g)
+        labels = torch.randint(0, 2, (B,), generator=g)
+        cases.append((logits, labels))
+    tied = torch.tensor([[0.5, 0.5], [1.0, -1.0], [1.0, -1.0], [-2.0, 2.0], [-2.0, 2.0], [0.0, 0.0]])
+    cases.append((tied, torch.tensor([1, 0, 1, 1, 0, 0])))
+    cases.append((torch.randn(9, 2, generator=g), torch.ones(9, dtype=torch.int64)))      # no negatives
+    cases.append((torch.randn(9, 2, generator=g), torch.zeros(9, dtype=torch.int64)))     # no positives
+    for logits, labels in cases:
+        m = R.binary_step_metrics(logits, labels)
+        y = labels.numpy()
+        pred = torch.argmax(logits, dim=1).numpy()
+        assert m["counts"] == tuple(int(v) for v in skm.confusion_matrix(y, pred, labels=[0, 1]).ravel())
+        assert abs(m["acc"] - skm.accuracy_score(y, pred)) < 1e-12
+        assert abs(m["prec"] - skm.precision_score(y, pred, zero_division=0)) < 1e-12
+        assert abs(m["rec"] - skm.recall_score(y, pred, zero_division=0)) < 1e-12
+        assert abs(m["spec"] - skm.recall_score(1 - y, 1 - pred, zero_division=0)) < 1e-12
+        assert abs(m["f1"] - skm.f1_score(y, pred, zero_division=0)) < 1e-12
+        assert abs(m["npv"] - skm.precision_score(1 - y, 1 - pred, zero_division=0)) < 1e-12
+        if 0 < y.sum() < len(y):
+            prob = torch.softmax(logits.float(), dim=1)[:, 1].numpy()
+            assert abs(m["auc_roc"] - skm.roc_auc_score(y, prob)) < 1e-12
+        else:
+            assert m["auc_roc"] == 0.0
+    ep = R.epoch_metrics(cases)
+    n = sum(len(l) for _, l in cases)
+    assert abs(ep["acc"] - sum(R.binary_step_metrics(a, b)["acc"] * len(b) for a, b in cases) / n) < 1e-12
