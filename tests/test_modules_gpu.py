@@ -286,3 +286,40 @@ def test_model_vit_vs_reference_golden_and_emulation(golden_dir):
     for k, p in model.named_parameters():
         ref_n = float(g[f"gnorm/{k}"])
         assert abs(float(p.grad.double().norm()) - ref_n) <= 0.03 * ref_n + 1e-7, k
+
+
+def test_checkpoint_round_trip_in_lightning_layout(tmp_path):
+    """main_mist.py:174-180 restores `torch.load(ckpt)["state_dict"]` into the model.  The flat fp32 / bf16 weight
+    buffers (functional.FlatWeights) must be invisible to that: same keys and shapes as the reference's state dict, a
+    saved file loads with weights_only=True into a fresh model AND into a model whose flat buffers are already live,
+    and both then compute exactly what the source model computes."""
+    import xvit
+    cfg = R.make_config("tiny")
+    img, labels = R.make_inputs(cfg, 3, seed=11)
+    img, labels = img.to(dev()), labels.to(dev())
+    torch.manual_seed(1)
+    src = xvit.ModelCross(cfg).to(dev())
+    opt = torch.optim.SGD(src.parameters(), lr=0.05)
+    for _ in range(2):                                   # train a little so the weights differ from any initialisation
+        opt.zero_grad()
+        src(img, labels)[1].backward()
+        opt.step()
+    src.eval()
+    ref_logits, ref_loss = src(img, labels)
+    sd = src.state_dict()
+    assert set(sd) == set(R.make_state_dict(cfg, seed=0))                       # the reference's key set (oracle state dict)
+    assert all(v.is_contiguous() for v in sd.values())
+    path = tmp_path / "epoch=0.ckpt"
+    torch.save({"state_dict": {k: v.cpu() for k, v in sd.items()}, "epoch": 0}, path)
+    loaded = torch.load(path, weights_only=True)["state_dict"]
+
+    fresh = xvit.ModelCross(cfg).to(dev())
+    fresh.load_state_dict(loaded, strict=True)
+    fresh.eval()
+    live = xvit.ModelCross(cfg).to(dev())
+    live.eval()
+    live(img, labels)                                    # flat buffers + bf16 operand copies now exist for the OLD weights
+    live.load_state_dict(loaded, strict=True)            # in-place copy into the flat views: the copies must be re-cast
+    for m in (fresh, live):
+        logits, loss = m(img, labels)
+        assert torch.equal(logits, ref_logits) and float(loss.detach()) == float(ref_loss.detach())
