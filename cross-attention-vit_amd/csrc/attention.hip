@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
 #pragma unroll
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[qb][1][i]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = half_max(mx);
       if (__any(mx > m_run[qb])) {   // some row's running max moved: rescale (otherwise alpha == 1 exactly, skip the pass)
         const float m_new = fmaxf(m_run[qb], mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
@@ -305,23 +305,26 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
 #pragma unroll
         for (int i = 0; i < 16; ++i) { oacc[qb][0][i] *= alpha; oacc[qb][1][i] *= alpha; }
       }
-      const float mc = m_run[qb] * c;
-      float psum = 0.f;
+      // p = exp2(s c - m c), two scores per v_pk_fma_f32 / v_pk_add_f32 (the loop is bound by VALU issue, not by MFMA)
+      const f32x2 c2 = {c, c}, nmc2 = {-m_run[qb] * c, -m_run[qb] * c};
+      f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[qb][0][i], c, -mc));
-        s[qb][0][i] = pv;
-        psum += pv;
+      for (int i = 0; i < 8; ++i) {
+        const f32x2 t = f32x2{s[qb][0][2 * i], s[qb][0][2 * i + 1]} * c2 + nmc2;
+        const f32x2 pv = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+        s[qb][0][2 * i] = pv.x; s[qb][0][2 * i + 1] = pv.y;
+        psum2 += pv;
       }
       if (two) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float pv = __builtin_amdgcn_exp2f(fmaf(s[qb][1][i], c, -mc));
-          s[qb][1][i] = pv;
-          psum += pv;
+        for (int i = 0; i < 8; ++i) {
+          const f32x2 t = f32x2{s[qb][1][2 * i], s[qb][1][2 * i + 1]} * c2 + nmc2;
+          const f32x2 pv = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+          s[qb][1][2 * i] = pv.x; s[qb][1][2 * i + 1] = pv.y;
+          psum2 += pv;
         }
       }
-      l_run[qb] += psum;
+      l_run[qb] += psum2.x + psum2.y;
     }
 #ifdef XVIT_DEBUG_ATTN_TIMES
     if (t == 3) { asm volatile("s_nop 0" ::"v"(s[0][0][0]), "v"(s[0][1][15])); tk[3] = __builtin_readcyclecounter(); }
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
 #endif
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    const float l_tot = half_sum(l_run[qb]);
     const int qrow = q0 + qb * 32 + (lane & 31);
     const bool valid = qrow < N;
     if (valid && h == 0) lse[((int64_t)b * H + head) * N + qrow] = m_run[qb] * scale + __logf(l_tot);
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
       for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(vimg, kb, ks), dof[ks], ks == 0 ? ZERO16 : dp, 0, 0, 0);
       // keys past N have K = V = 0 (zero-filled by the DMA), so they add nothing to dQ
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < 16; ++i) {   // (hand-packed v_pk_fma / v_pk_mul here measured 4 % slower at N = 4097: left to the compiler)
         const float pv = __builtin_amdgcn_exp2f(fmaf(s[i], c, nlse));
         s[i] = pv * (dp[i] - dlt);  // dS^T
       }

@@ -93,6 +93,31 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Combine a value across the two 32-lane halves of a wave (lane l with lane l ^ 32) in ONE VALU instruction:
+// v_permlane32_swap exchanges the upper half of one register with the lower half of another, so afterwards the pair
+// holds (x.lo, x.lo) and (x.hi, x.hi).  __shfl_xor(x, 32) compiles to a ds_bpermute round trip through the LDS
+// pipe (address arithmetic + lgkmcnt wait) instead.
+// (Note for anyone touching this: __builtin_bit_cast(float, vec.y) on an ext-vector ELEMENT reads element 0 with this
+// hipcc — go through a scalar temporary, as below.)
+__device__ __forceinline__ void swap_halves(float x, float& lo, float& hi) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t_;
+  const unsigned bits = __builtin_bit_cast(unsigned, x);
+  const u32x2_t_ r = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+  const unsigned r0 = r.x, r1 = r.y;
+  lo = __builtin_bit_cast(float, r0);
+  hi = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ float half_max(float x) {
+  float lo, hi;
+  swap_halves(x, lo, hi);
+  return fmaxf(lo, hi);
+}
+__device__ __forceinline__ float half_sum(float x) {
+  float lo, hi;
+  swap_halves(x, lo, hi);
+  return lo + hi;
+}
+
 // Exact-form (erf) GELU and its derivative in fp32.  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // i.e. fp32 round-off level; libm erff costs ~4x the VALU work and the epilogue is VALU-bound):
 //   erf(u) = 1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) e^{-u^2},  t = 1 / (1 + p u),  u >= 0.

@@ -285,7 +285,17 @@ def test_model_vit_vs_reference_golden_and_emulation(golden_dir):
     assert rel(logits, emu_logits) < 2.5e-2 and abs(float(loss.detach()) - float(emu_loss)) < 2e-3
     for k, p in model.named_parameters():
         ref_n = float(g[f"gnorm/{k}"])
-        assert abs(float(p.grad.double().norm()) - ref_n) <= 0.03 * ref_n + 1e-7, k
+        tol = 0.03
+        if k == "mlp_head.4.bias":
+            # the bias of the last Linear: dL/db = mean_b(softmax(logits_b) - target_b) is a closed form of OUR logits, so the
+            # backward itself is checked exactly; against the reference's value this 2-element tensor inherits the logits'
+            # own bf16 deviation (gate 2.5e-2 above) times |dp/dlogit| / |p - y| at batch 3, i.e. several per cent
+            eps = float(getattr(cfg, "label_smoothing", 0.0))
+            target = torch.nn.functional.one_hot(labels.to(dev()), logits.shape[1]).float() * (1.0 - eps) + eps / logits.shape[1]
+            want = (torch.softmax(logits.detach().float(), dim=1) - target).mean(0)
+            assert rel(p.grad, want) < 1e-4, rel(p.grad, want)
+            tol = 0.08
+        assert abs(float(p.grad.double().norm()) - ref_n) <= tol * ref_n + 1e-7, k
 
 
 def test_checkpoint_round_trip_in_lightning_layout(tmp_path):
