@@ -20,7 +20,11 @@ constexpr int DH = 64;          // head dim
 constexpr int TILE_ROWS = 64;   // streamed rows per iteration
 constexpr int IMG_BYTES = TILE_ROWS * DH * 2;  // 8 KiB
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int FWD_NST = 3;     // K/V ring depth of the forward kernel (prefetch distance 2 tiles)
+#ifndef XVIT_FWD_NST
+#define XVIT_FWD_NST 2
+#endif
+constexpr int FWD_NST = XVIT_FWD_NST;     // K/V ring depth of the forward kernel.  2 stages = 32 KiB of LDS: four blocks per CU (the VGPR budget
+                                          // of 128 allows exactly that) hide each other's prologues; 3 stages (3 blocks per CU) measured 3-4.5 % slower
 
 // chunk swizzle for a [rows][128 B] image: conflict-free for b128 row reads and tr reads
 __device__ __forceinline__ int swz_img(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
@@ -234,8 +238,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
   int stage = 0;
   for (int t = 0; t < ntiles; ++t) {
     TK(0)
-    if (t + 1 < ntiles) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile t landed; t+1 may be in flight
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ring_wait<FWD_NST, 4>(t, ntiles);   // tile t landed; up to FWD_NST - 2 younger tiles may be in flight
     __builtin_amdgcn_s_barrier();   // every wave's pieces of tile t are in LDS; every wave is done with tile t-1
     TK(1)
     if (t + FWD_NST - 1 < ntiles) {
