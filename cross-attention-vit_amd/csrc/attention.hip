@@ -400,6 +400,7 @@ __global__ void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __rest
 // ------------------------------------------------------------------------------------------
 // backward, dQ: one wave = 32 queries, streams K and V tiles
 // ------------------------------------------------------------------------------------------
+// (133 VGPRs: three blocks per CU; squeezing it to 128 for a fourth spills and measured 6 % slower)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                              int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
                                                              const float* __restrict__ nlse_ws, const float* __restrict__ delta,
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 // ------------------------------------------------------------------------------------------
 constexpr int DKV_STAGE = 2 * IMG_BYTES + 512;  // Q image | dO image | nlse[64] | delta[64]  (all four arrive by LDS-DMA)
 
+// (198 VGPRs: two blocks per CU; bounding it to 168 for a third spills and measured 7 % slower)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                               int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
                                                               const float* __restrict__ nlse_ws, const float* __restrict__ delta,
