@@ -12,7 +12,7 @@ from xvit import ops  # noqa: E402
 
 def main():
     dev = torch.device("cuda:0")
-    for B, N in ((32, 512), (32, 513), (4, 4097)):
+    for B, N in ((126, 513), (32, 512), (32, 513), (4, 4097)):
         H, d = 12, 768
         qkv = torch.randn(B, N, 3 * d, device=dev).bfloat16()
         for _ in range(3):
@@ -42,7 +42,7 @@ def dkv_times():
     """Same for the dK/dV kernel (stamps land in the delta workspace)."""
     from xvit import _lib
     dev = torch.device("cuda:0")
-    for B, N in ((32, 512), (32, 513), (4, 4097)):
+    for B, N in ((126, 513), (32, 512), (32, 513), (4, 4097)):
         H, d, dh = 12, 768, 64
         qkv = torch.randn(B * N, 3 * d, device=dev).bfloat16()
         o, lse = ops.attn_fwd(qkv, B, N, H, 0.125)
