@@ -110,6 +110,44 @@ def cpu_baseline(cfg, seconds_budget=25.0):
             "sample": f"oracle/ref_cpu.py fwd+bwd fp32, same config, batch {B}, median of {len(times)} steps after 1 warm-up ({med * 1e3:.0f} ms/step)"}
 
 
+def clock_probe(step, seconds=1.5):
+    """Sustained shader clock while the step runs (price the roofline against the peak at the measured clock as
+    well).  Runs UNTIMED extra steps and samples `rocm-smi --showclocks` from a side thread; any failure returns None."""
+    import re
+    import subprocess
+    import threading
+    samples, stop = [], threading.Event()
+
+    def sample():
+        while not stop.is_set():
+            try:
+                txt = subprocess.run(["rocm-smi", "--showclocks", "-d", os.environ.get("LOCAL_RANK", "0")], capture_output=True, text=True, timeout=5).stdout
+                m = re.search(r"sclk clock level[^\n]*\((\d+)Mhz\)", txt)
+                if m:
+                    samples.append(int(m.group(1)))
+            except Exception:
+                return
+            stop.wait(0.15)
+
+    th = threading.Thread(target=sample, daemon=True)
+    try:
+        th.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+    finally:
+        stop.set()
+        th.join(timeout=6)
+    busy = sorted(v for v in samples if v > 500)          # idle samples (~100 MHz) bracket the run
+    if not busy:
+        return None
+    mhz = busy[len(busy) // 2]
+    return {"sclk_mhz": mhz, "of_2400_mhz_spec": round(mhz / 2400.0, 3), "samples": len(busy),
+            "note": "median rocm-smi sclk over untimed extra steps; the MFMA peak used above assumes 2.4 GHz"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +158,7 @@ def main():
                     "= 2.96 .. 11.9 rounds of 256 CUs, so the last round of every launch is nearly full")
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the untimed sustained-clock measurement")
     ap.add_argument("--detail", action="store_true", help="per-shape GEMM table on stderr (diagnostic)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (xvit.graph.GraphedStep); "
                     "pays off when the step is host-bound, i.e. at small per-GPU batch")
@@ -280,6 +319,10 @@ def main():
         if "attn_fwd" in kernels:
             out["attention_mfma_frac"] = {"fwd": kernels["attn_fwd"]["frac"], "bwd": kernels.get("attn_bwd", {}).get("frac")}
 
+    if rank == 0 and world == 1 and not args.no_clock_probe:
+        out["clock"] = clock_probe(step)
+        if out["clock"] and "roofline" in out and out["roofline"]["bound"] == "mfma":
+            out["roofline"]["frac_at_measured_clock"] = round(out["roofline"]["frac"] / out["clock"]["of_2400_mhz_spec"], 4)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
