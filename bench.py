@@ -265,22 +265,30 @@ def main():
     # ---- per-kernel pricing with HIP events on the launch stream (rank 0) --------------------
     if args.graph:
         step = eager_step                             # per-kernel pricing needs individual launches
-    if rank == 0 and args.profile_steps > 0:
+    rec = None
+    if args.profile_steps > 0:
         # kernels are priced one at a time: the two modality streams are merged for these extra steps, otherwise
-        # concurrently running kernels stretch each other's event brackets (the timed region above keeps them)
+        # concurrently running kernels stretch each other's event brackets (the timed region above keeps them).
+        # EVERY rank runs the same extra steps (their backward launches the reducer's collectives from its hooks, so a
+        # rank running them alone would wait for its peers forever); only rank 0 records.
         prev_streams = os.environ.get("XVIT_STREAMS")
         os.environ["XVIT_STREAMS"] = "0"
         step()
         torch.cuda.synchronize(dev)
-        ops.PROFILE, ops.PROFILE_SHAPES = [], args.detail
+        if rank == 0:
+            ops.PROFILE, ops.PROFILE_SHAPES = [], args.detail
         for _ in range(args.profile_steps):
             step()
         torch.cuda.synchronize(dev)
-        rec, ops.PROFILE = ops.PROFILE, None
+        if rank == 0:
+            rec, ops.PROFILE = ops.PROFILE, None
         if prev_streams is None:
             os.environ.pop("XVIT_STREAMS")
         else:
             os.environ["XVIT_STREAMS"] = prev_streams
+        if use_dist:
+            dist.barrier()
+    if rec is not None:
         if args.detail:
             det = {}
             for name, work, kind, s, e in rec:
