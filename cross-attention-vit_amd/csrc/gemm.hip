@@ -427,8 +427,27 @@ struct BigEpi {
   uint32_t c_step, aux_step, res_step, slab_step, c_gap, res_wrap;
 };
 
+// The z loads of the GELU' epilogue are software-pipelined one region (4 bodies) ahead of the stores (two regions ahead measured the same): on gfx9 loads and
+// stores retire through ONE in-order vmcnt, so a load issued right after a region's stores can only be waited for once
+// those stores have been acknowledged by memory.  Loading z inside each body cost the GELU' dgrad ~15 us per tile round
+// (505 TFLOP/s where the same shape without an epilogue load reaches 860).  LoadCursor is a second copy of the row state
+// that runs one region ahead of the store cursor in BigEpi.  (The fp32 residual loads of the out-proj / FFN2 epilogues
+// stay in the body: those epilogues are bound by their 8 B/element of HBM traffic, and prefetching them as well doubled
+// the number of inlined epilogue variants — minutes of compile time and register spills.)
+struct LoadCursor { uint32_t row, aux; };
+struct EpiLoads { u32x2_t aux[4]; };
+
+__device__ __forceinline__ void big_epi_issue_aux(const GemmParams& p, const BigEpi& e, LoadCursor& lc, EpiLoads& L) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const bool ok = e.col_ok && lc.row < (uint32_t)p.M;
+    L.aux[b] = __builtin_amdgcn_raw_buffer_load_b64(e.raux, ok ? lc.aux : OOB, 0, 0);
+    lc.row += 4; lc.aux += e.aux_step;
+  }
+}
+
 template <int ACT, bool DROP>
-__device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32x4 v) {
+__device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32x4 v, u32x2_t auxv) {
   const bool ok = e.col_ok && e.row < (uint32_t)p.M;
   if (e.to_slab) {   // split-K partial sums, [M][N] fp32
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rslab, ok ? e.slab : OOB, 0, 0);
@@ -442,7 +461,7 @@ __device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
     } else if (ACT == XVIT_ACT_DGELU) {
-      const bf16x4 z = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(e.raux, ok ? e.aux : OOB, 0, 0));
+      const bf16x4 z = __builtin_bit_cast(bf16x4, auxv);
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] *= dgelu_f(bf2f(z[c]));
     }
@@ -471,26 +490,37 @@ __device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32
   if (e.srem >= e.smod) { e.srem -= e.smod; e.c += e.c_gap; }
 }
 
-// rows 64 HALF .. 64 HALF + 63 of the wave's tile: accumulators -> LDS (column-wise) -> 16 bodies (row-wise)
-template <int ACT, bool DROP, int HALF>
-__device__ __forceinline__ void big_epi_half(const GemmParams& p, BigEpi& e, const f32x4 (&acc)[8][4], XVIT_LDS char* slice, const uint32_t (&woff)[4],
-                                             const uint32_t (&roff)[4]) {
+// Region R (0..7) of the wave's 128-row tile = 4 bodies = rows 16 R .. 16 R + 15; regions 0-3 and 4-7 share one LDS
+// transpose pass each (64 rows: accumulators -> LDS column-wise, read back row-wise).  `cur` holds this region's
+// pre-issued z loads (GELU' only); the next region's are issued before this region's stores.
+template <int ACT, bool DROP, int R>
+__device__ __forceinline__ void big_epi_regions(const GemmParams& p, BigEpi& e, LoadCursor& lc, EpiLoads& cur, const f32x4 (&acc)[8][4], XVIT_LDS char* slice,
+                                                const uint32_t (&woff)[4], const uint32_t (&roff)[4]) {
+  if constexpr ((R & 3) == 0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *(XVIT_LDS f32x4*)(slice + i * 4096 + woff[j]) = acc[HALF * 4 + i][j];
-#pragma unroll
-  for (int it = 0; it < 16; ++it) {
-    const f32x4 v = *(const XVIT_LDS f32x4*)(slice + it * 1024 + roff[it & 3]);
-    big_epi_body<ACT, DROP>(p, e, v);
-    if ((it & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // 4 bodies (4-8 loads in flight) per scheduling region
+      for (int j = 0; j < 4; ++j) *(XVIT_LDS f32x4*)(slice + i * 4096 + woff[j]) = acc[(R >> 2) * 4 + i][j];
   }
+  EpiLoads nxt;
+  if constexpr (ACT == XVIT_ACT_DGELU && R < 7) big_epi_issue_aux(p, e, lc, nxt);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const int it = (R & 3) * 4 + b;
+    const f32x4 v = *(const XVIT_LDS f32x4*)(slice + it * 1024 + roff[it & 3]);
+    big_epi_body<ACT, DROP>(p, e, v, cur.aux[b]);
+  }
+  __builtin_amdgcn_sched_barrier(0);   // one region per scheduling window
+  if constexpr (R < 7) big_epi_regions<ACT, DROP, R + 1>(p, e, lc, nxt, acc, slice, woff, roff);
 }
+
 template <int ACT, bool DROP>
 __device__ __forceinline__ void big_epilogue(const GemmParams& p, BigEpi& e, const f32x4 (&acc)[8][4], XVIT_LDS char* slice, const uint32_t (&woff)[4],
                                              const uint32_t (&roff)[4]) {
-  big_epi_half<ACT, DROP, 0>(p, e, acc, slice, woff, roff);
-  big_epi_half<ACT, DROP, 1>(p, e, acc, slice, woff, roff);
+  LoadCursor lc = {e.row, e.aux};
+  EpiLoads first;
+  if constexpr (ACT == XVIT_ACT_DGELU) big_epi_issue_aux(p, e, lc, first);
+  big_epi_regions<ACT, DROP, 0>(p, e, lc, first, acc, slice, woff, roff);
 #ifndef XVIT_DEBUG_TIMES   // (that build borrows p.colsum as its timestamp buffer)
   if (p.colsum && !e.to_slab) {   // += column sums of the stored tile: lanes l, l+16, l+32, l+48 share their 4 columns
 #pragma unroll
