@@ -36,7 +36,7 @@ import torch.distributed as dist  # noqa: E402
 # HBM bytes per launch of the dominant kernel family, from the rocprofv3 --pmc passes committed under profiles/
 # (FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE), averaged over the family's launches
 # of one step at the default batch.  Filled in from profiles/r01_pmc_traffic.md; None = not measured.
-TRAFFIC = {"gemm_big_nt": 8.41e8, "gemm_big_nn": 6.66e8, "gemm_big_tn+splitk": 5.95e8}   # bytes per launch at the default batch (126): profiles/r01_c_summary.md
+TRAFFIC = {"gemm_big_nt": 8.52e8, "gemm_big_nn": 6.38e8, "gemm_big_tn+splitk": 5.95e8}   # bytes per launch at the default batch (126): profiles/r01_c_summary.md
 
 MFMA_PEAK_TF = 2516.0   # bf16 dense, MI355X_MICROARCH.md: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0   # HBM3E spec

@@ -62,7 +62,7 @@ def main():
              f"CPU oracle {cb['value']} {cb['unit']} on {cb['cores']} host cores ({cb['sample']}).\n")
     L.append(f"`roofline`: `{rf['kernel']}` — {rf['achieved']} {rf['unit']} algorithmic = {100 * rf['frac']:.1f} % of peak, average launch {rf['avg_launch_us']} us by HIP events.\n")
     L.append("## Kernel time\n")
-    L.append("`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 0 --single-stream` "
+    L.append("`rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-clock-probe --profile-steps 0 --single-stream` "
              f"({steps} steps; `--single-stream` merges the two modality streams so a kernel's duration is not stretched by a concurrently running one; raw CSV: `{tag}_kernel_stats.csv`).\n")
     L.append("| kernel | calls | avg us | total ms | % of GPU time |\n|---|---|---|---|---|")
     for r in rows[:26]:
@@ -73,7 +73,7 @@ def main():
     for k, v in bench["kernels"].items():
         L.append(f"| {k} | {v['launches_per_step']} | {v['avg_us']} | {100 * v['share_of_kernel_time']:.1f} % | {v['achieved']} {v['unit']} | {100 * v['frac']:.1f} % |")
     L.append("\n## HBM traffic per launch (PMC)\n")
-    L.append("Separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over `bench.py --steps 2 --warmup 1 --no-cpu-baseline --profile-steps 0`; "
+    L.append("Separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes over `bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-clock-probe --profile-steps 0`; "
              "counter unit KB; FETCH_SIZE doubled (gfx950 tallies the 128-B requests of 16-B/lane streams as 64 B, MI355X_MICROARCH.md §HBM); per launch, "
              "averaged over all shapes of the kernel in a step.\n")
     L.append("| kernel | launches sampled | 2 x FETCH (MB) | WRITE (MB) | HBM MB / launch |\n|---|---|---|---|---|")
