@@ -184,14 +184,18 @@ def test_model_cross_vs_bf16_emulating_oracle(name, batch):
     assert abs(float(loss) - float(ref_loss)) < 2e-3
 
 
-def test_unobserved_last_block_cls_only_path_matches_full_path():
+@pytest.mark.parametrize("name,over", [("tiny", {}), ("small", {}),
+                                       ("tiny", dict(num_modalities=4, attn_order={"0": "1", "1": "2", "2": "3", "3": "0"})),
+                                       ("tiny", dict(num_modalities=3, attn_order={"0": "2"}))])   # modalities 1 and 2 have no fusion of their own
+def test_unobserved_last_block_cls_only_path_matches_full_path(name, over):
     """ModelCross runs its last MultiScaleBlock CLS-only when nothing observes the block's output (the heads read
     x[m][:, 0] only, model_cross.py:203); with a forward hook it produces the reference's full token tensors.  Both
     paths must give the same logits, loss and parameter gradients."""
     import xvit
-    cfg = R.make_config("tiny")
+    cfg = R.make_config(name, **over)
     img, labels = R.make_inputs(cfg, 3, seed=5)
     img, labels = img.to(dev()), labels.to(dev())
+    torch.manual_seed(2)
     model = xvit.ModelCross(cfg).to(dev())
     model.train()
 
@@ -211,6 +215,33 @@ def test_unobserved_last_block_cls_only_path_matches_full_path():
     assert torch.equal(l_full, l_cls) and loss_full == loss_cls      # the CLS rows go through the very same kernels
     for k in g_full:
         assert rel(g_cls[k], g_full[k]) < 1e-5 or float(g_full[k].abs().max()) < 1e-6, k
+
+
+def test_partial_fusion_map_vs_bf16_emulating_oracle():
+    """attn_order need not cover every modality (model_cross.py:131-147: a modality without an entry passes through the
+    MultiScaleBlock unchanged).  3 modalities, only 0 <- 2 fused: forward vs the bf16-emulating oracle, gradients vs
+    the fp32 oracle's autograd (norms), with the unobserved (CLS-only last block) path."""
+    import xvit
+    cfg = R.make_config("tiny", num_modalities=3, attn_order={"0": "2"})
+    sd = R.make_state_dict(cfg, seed=3)
+    img, labels = R.make_inputs(cfg, 4, seed=8)
+    model = xvit.ModelCross(cfg).to(dev())
+    assert set(model.state_dict()) == set(sd)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    logits, loss = model(img.to(dev()), labels.to(dev()))
+    loss.backward()
+    with R.emulate_bf16():
+        ref_logits, ref_loss = R.model_cross_forward(sd, img, labels, cfg)
+    assert rel(logits, ref_logits) < 2.5e-2 and abs(float(loss.detach()) - float(ref_loss)) < 2e-3
+    _, _, grads = R.model_cross_loss_and_grads(sd, img, labels, cfg)
+    for k, p in model.named_parameters():
+        if k.endswith("wk.bias"):
+            assert float(p.grad.abs().max()) < 1e-3          # analytically zero (softmax shift invariance)
+            continue
+        ref_n = float(grads[k].double().norm())
+        got_n = float(p.grad.double().norm())
+        assert abs(got_n - ref_n) <= 0.05 * ref_n + 1e-6, (k, got_n, ref_n)
 
 
 def test_accumulates_like_autograd_and_fails_loudly_off_gpu():
