@@ -83,6 +83,35 @@ def main():
         _, wm = write[k]
         L.append(f"| `{k}` | {n} | {2 * fm:.1f} | {wm:.1f} | {2 * fm + wm:.1f} |")
     L.append("")
+    mf = sorted(glob.glob(os.path.join(sess, "mfma", "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
+    if mf:
+        acc, cnt, dur, seen = defaultdict(lambda: defaultdict(float)), defaultdict(int), defaultdict(float), set()
+        with open(mf[-1]) as f:
+            for r in csv.DictReader(f):
+                k = short(r["Kernel_Name"])
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                if r["Dispatch_Id"] not in seen:
+                    seen.add(r["Dispatch_Id"])
+                    cnt[k] += 1
+                    dur[k] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        L.append("## MFMA-pipe utilisation and wave states (PMC)\n")
+        L.append("`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU` over "
+                 "`bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-clock-probe --profile-steps 0 --single-stream`.  MFMA utilisation = "
+                 "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 256 CUs x 4 SIMDs): the gfx94x `MfmaUtil` formula with GRBM_GUI_ACTIVE, which rocprofv3 reports "
+                 "summed over the 8 XCDs, brought back to one clock domain (the implied clock is 2.2-2.3 GHz).  It counts EXECUTED matrix work at the clock the kernel "
+                 "actually ran at: padding tiles (N = 513 in 64 / 128-row tiles) and the S / dP recomputation of the two-kernel attention backward are included, which is why it "
+                 "sits above the algorithmic fractions in the table above.  `parked` = SQ_WAIT_ANY / SQ_WAVE_CYCLES (s_waitcnt, barriers), `issue-stalled` = "
+                 "SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, `VALU` = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES.\n")
+        L.append("| kernel | launches | avg us | MFMA-pipe utilisation | waves parked | issue-stalled | VALU active |\n|---|---|---|---|---|---|---|")
+        for k in sorted(acc, key=lambda k: -dur[k])[:9]:
+            a = acc[k]
+            gui, wc = a.get("GRBM_GUI_ACTIVE", 0.0), a.get("SQ_WAVE_CYCLES", 0.0)
+            if gui <= 0 or wc <= 0:
+                continue
+            util = a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8.0 * 1024.0)
+            L.append(f"| `{k}` | {cnt[k]} | {dur[k] / cnt[k] / 1e3:.1f} | {100 * util:.1f} % | {100 * a.get('SQ_WAIT_ANY', 0) / wc:.0f} % | "
+                     f"{100 * a.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} % | {100 * a.get('SQ_ACTIVE_INST_VALU', 0) / wc:.0f} % |")
+        L.append("")
     with open(os.path.join(out, f"{tag}_summary.md"), "w") as f:
         f.write("\n".join(L))
     print("\n".join(L))
