@@ -148,6 +148,83 @@ def clock_probe(step, seconds=1.5):
             "note": "median rocm-smi sclk over untimed extra steps; the MFMA peak used above assumes 2.4 GHz"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks ourselves (one process per GPU, RCCL)
+    and pass rank 0's JSON line through.  Runs BEFORE this process touches the GPU (it never does): the children are
+    fresh processes started by `python -m torch.distributed.run`, exactly the command line the driver uses."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC only on this pool (RCCL needs it)
+    log(f"launching {n} ranks: {' '.join(cmd[1:9])} ...")
+    return subprocess.run(cmd, env=env).returncode          # stdout/stderr inherited: rank 0 prints the one JSON line
+
+
+def dry_run(args, rank, world):
+    """XVIT_BENCH_DRYRUN=1: the launch / rendezvous / one-JSON-line flow without any GPU work (gloo), so the N>1 path of
+    this file is exercised by the CPU test suite (tests/test_bench_launch.py)."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = [None] * world
+    dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "world": world, "pid": os.getpid()})
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks": seen}), flush=True)
+    dist.destroy_process_group()
+
+
+def small_batch_points(model, cfg, dev, P, batches, steps=12):
+    """Same step at the reference's batch sizes, eager and as ONE HIP-graph replay (xvit.graph.GraphedStep): below
+    ~B=32 the eager step is bound by host launch issue, which the graph removes.  Extra keys only — `value` stays the
+    headline batch."""
+    import xvit
+    from xvit.graph import GraphedStep
+    pts = {}
+    M = cfg.num_modalities
+    params = list(model.parameters())
+    for B in batches:
+        gen = torch.Generator().manual_seed(77 + B)
+        img = torch.randn(B, M, 1, *cfg.img_size, generator=gen).to(dev, torch.bfloat16)
+        labels = torch.randint(0, cfg.num_classes, (B,), generator=gen).to(dev)
+
+        def eager():
+            for p in params:
+                p.grad = None
+            xvit.invalidate_shadows()
+            model(img, labels)[1].backward()
+
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / steps
+
+        te = timed(eager)
+        entry = {"eager_ms": round(te * 1e3, 3), "eager_tokens_per_s": round(B * M * P / te, 1)}
+        try:
+            g = GraphedStep(model, img, labels)
+            tg = timed(lambda: g())
+            entry.update(graph_ms=round(tg * 1e3, 3), graph_tokens_per_s=round(B * M * P / tg, 1))
+            del g
+        except Exception as exc:   # capture is an optimisation: report, never fail the bench line
+            entry["graph_error"] = f"{type(exc).__name__}: {exc}"[:200]
+        pts[f"B{B}"] = entry
+        log(f"small batch B={B}: {entry}")
+    for p in params:
+        p.grad = None
+    return pts
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,6 +236,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the untimed sustained-clock measurement")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the extra B=8 / B=32 points (eager and HIP-graph replay)")
     ap.add_argument("--detail", action="store_true", help="per-shape GEMM table on stderr (diagnostic)")
     ap.add_argument("--graph", action="store_true", help="replay the step as one captured HIP graph (xvit.graph.GraphedStep); "
                     "pays off when the step is host-bound, i.e. at small per-GPU batch")
@@ -168,13 +246,14 @@ def main():
 
     if args.single_stream:
         os.environ["XVIT_STREAMS"] = "0"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
-        args.gpus = world
+    args.gpus = world
+    if os.environ.get("XVIT_BENCH_DRYRUN") == "1":
+        return dry_run(args, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("XVIT_FORCE_DIST") == "1"   # the latter: rehearse the N>1 code path on one GPU
@@ -261,6 +340,13 @@ def main():
         "loss": round(loss_val, 5),
         "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2**30, 1),
     }
+    if use_dist:
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            ver = None
+        out["collective"] = {"backend": dist.get_backend(), "rccl_version": ver, "ranks": dist.get_world_size(),
+                             "buckets": len(reducer.buckets), "bucket_mib": 32, "exposed_launches": reducer.exposed_launches}
 
     # ---- per-kernel pricing with HIP events on the launch stream (rank 0) --------------------
     if args.graph:
@@ -327,6 +413,9 @@ def main():
         if "attn_fwd" in kernels:
             out["attention_mfma_frac"] = {"fwd": kernels["attn_fwd"]["frac"], "bwd": kernels.get("attn_bwd", {}).get("frac")}
 
+    # ---- the reference's own batch sizes (main_mist.py:206 trains at 8 per GPU), next to the headline batch -------------
+    if world == 1 and not use_dist and not args.no_small_batch:
+        out["small_batch"] = small_batch_points(model, cfg, dev, P, (8, 32))
     if rank == 0 and world == 1 and not args.no_clock_probe:
         out["clock"] = clock_probe(step)
         if out["clock"] and "roofline" in out and out["roofline"]["bound"] == "mfma":

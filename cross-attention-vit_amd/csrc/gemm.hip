@@ -11,6 +11,8 @@
 // Epilogue: accumulators -> wave-private LDS slab -> row-contiguous 16-B accesses.
 #include "xvit_common.h"
 
+#include <mutex>
+
 namespace xvit {
 
 struct GemmParams {
@@ -796,16 +798,15 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
   hipStream_t s = (hipStream_t)stream;
 
-  static bool attr_done = false;
-  if (!attr_done) {
+  static std::once_flag attr_once;   // the library is re-entrant: concurrent first calls from several host threads
+  std::call_once(attr_once, [] {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-    attr_done = true;
-  }
+  });
   if (big) {
     p.ntm = (a->M + TBM - 1) / TBM; p.ntn = (a->N + TBN - 1) / TBN;
     const dim3 grid(p.ntm * p.ntn, 1, a->batch * a->split_k), block(512);

@@ -148,6 +148,22 @@ class CrossAttentionBlock(nn.Module):
         return XF.CrossFusionFn.apply(x, x, *_fusion_args(self), False, _p(self, self.attn.fn.attn_drop))
 
 
+_SIDE_STREAMS: dict = {}
+
+
+def _side_streams(device, n):
+    """Per-device pool of side streams for the modality branches / fusions (shared by every model in the process)."""
+    key = (device, n)
+    if key not in _SIDE_STREAMS:
+        if os.environ.get("XVIT_CU_SPLIT", "0") == "1":   # each branch owns 1/n of the CUs (see xvit/cu_mask.py)
+            from . import cu_mask
+            n_cu = torch.cuda.get_device_properties(device).multi_processor_count
+            _SIDE_STREAMS[key] = [cu_mask.masked_stream(device, bits) for bits in cu_mask.split_masks(n_cu, n)]
+        else:
+            _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _SIDE_STREAMS[key]
+
+
 class MultiScaleBlock(nn.Module):
     """model_cross.py:116-148: list of M token tensors in, list out."""
 
@@ -158,41 +174,38 @@ class MultiScaleBlock(nn.Module):
         self.blocks = nn.ModuleList(branch() for _ in range(config.num_modalities))   # separate weights per modality
         self.fusion = nn.ModuleList(CrossAttentionBlock(config) for _ in self.attn_order)
 
-    _streams: dict = {}
-
-    @classmethod
-    def _branch_streams(cls, device, n):
-        key = (device, n)
-        if key not in cls._streams:
-            if os.environ.get("XVIT_CU_SPLIT", "0") == "1":   # each branch owns 1/n of the CUs (see xvit/cu_mask.py)
-                from . import cu_mask
-                n_cu = torch.cuda.get_device_properties(device).multi_processor_count
-                cls._streams[key] = [cu_mask.masked_stream(device, bits) for bits in cu_mask.split_masks(n_cu, n)]
-            else:
-                cls._streams[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
-        return cls._streams[key]
-
     def _parallel(self, thunks, tensors, kind="branches"):
         """Run independent pieces of work (one per modality) each on its own HIP stream so their kernels interleave
         on the chip (one GEMM's tail round / HBM-bound epilogue overlaps the other's MFMA phase, and the strings of
-        tiny CLS-row launches of the two fusions overlap each other).  `tensors` are the inputs the side streams
-        read.  autograd replays backward on the same streams."""
+        tiny CLS-row launches of the two fusions overlap each other).  `thunks[i]` is None for a pass-through (nothing
+        to launch: no fork).  `tensors` are the inputs the side streams read.  autograd replays backward on the same
+        streams."""
         mode = os.environ.get("XVIT_STREAMS", "1")     # "1": branches and fusions, "branches": branches only, "0": one stream
-        if len(thunks) < 2 or not tensors[0].is_cuda or mode == "0" or (mode == "branches" and kind != "branches"):
-            return [f() for f in thunks]
+        work = [i for i, f in enumerate(thunks) if f is not None]
+        outs = [None] * len(thunks)
+        if len(work) < 2 or not tensors[0].is_cuda or mode == "0" or (mode == "branches" and kind != "branches"):
+            for i in work:
+                outs[i] = thunks[i]()
+            return outs
         dev = tensors[0].device
         cur = torch.cuda.current_stream(dev)
-        streams = self._branch_streams(dev, len(thunks))
-        outs = []
-        for f, st in zip(thunks, streams):
+        streams = _side_streams(dev, len(thunks))
+        # While a HIP graph is being captured every tensor lives in the graph's private pool and the order of the replayed
+        # work is fixed by the captured fork/join edges: record_stream (an allocator hint for eager reuse) has nothing to
+        # protect there, and its deferred-event bookkeeping on pool blocks is what capture_end tripped over.
+        capturing = torch.cuda.is_current_stream_capturing()
+        for i in work:
+            st = streams[i]
             st.wait_stream(cur)
-            for t in tensors:
-                t.record_stream(st)
+            if not capturing:
+                for t in tensors:
+                    t.record_stream(st)
             with torch.cuda.stream(st):
-                outs.append(f())
-        for y, st in zip(outs, streams):
-            cur.wait_stream(st)
-            y.record_stream(cur)
+                outs[i] = thunks[i]()
+        for i in work:
+            cur.wait_stream(streams[i])
+            if not capturing:
+                outs[i].record_stream(cur)
         return outs
 
     def _branches(self, x):
@@ -213,8 +226,9 @@ class MultiScaleBlock(nn.Module):
                 thunks.append(lambda i=i, j=j, blk=blk: XF.CrossFusionFn.apply(attn[i], attn[j], *_fusion_args(blk), not cls_only, _p(blk, blk.attn.fn.attn_drop)))
                 cross_count += 1
             else:
-                thunks.append(lambda i=i: attn[i])
-        return self._parallel(thunks, list(attn), kind="fusion")   # the fusions only read the branch outputs: independent of each other
+                thunks.append(None)                                    # no fusion for this modality: its tokens pass through (:146)
+        outs = self._parallel(thunks, list(attn), kind="fusion")   # the fusions only read the branch outputs: independent of each other
+        return [attn[i] if o is None else o for i, o in enumerate(outs)]
 
 
 class ModelCross(EpochStatsMixin, _Base):

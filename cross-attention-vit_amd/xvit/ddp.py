@@ -20,7 +20,7 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("params", "flat", "views", "pending", "work", "launched")
+    __slots__ = ("params", "flat", "views", "pending", "work", "launched", "events")
 
     def __init__(self, params, device):
         self.params = params
@@ -31,6 +31,24 @@ class _Bucket:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
             o += p.numel()
         self.pending, self.work, self.launched = len(params), None, False
+        self.events = {}      # stream id -> (stream, event): the latest gradient write of this bucket on each stream
+
+
+def plan_buckets(params, bucket_bytes: int):
+    """Partition `params` into buckets of >= bucket_bytes fp32 (the last one may be smaller), walking the list in
+    REVERSE registration order — approximately the order backward produces the gradients.  For ModelCross that is
+    heads -> final norms -> transformer.1 -> transformer.0 -> the shared cls_token / patch_to_embedding / pos_embedding
+    last (their gradients are complete only after the embed backward of every modality)."""
+    buckets, cur, size = [], [], 0
+    for p in reversed(list(params)):
+        cur.append(p)
+        size += p.numel() * 4
+        if size >= bucket_bytes:
+            buckets.append(cur)
+            cur, size = [], 0
+    if cur:
+        buckets.append(cur)
+    return buckets
 
 
 class BucketedGradReducer:
@@ -46,16 +64,7 @@ class BucketedGradReducer:
         if broadcast:  # replicas start identical (DDP does the same at wrap time)
             for p in params:
                 dist.broadcast(p.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
-        # buckets in reverse registration order ~= the order backward produces gradients
-        self.buckets, cur, size = [], [], 0
-        for p in reversed(params):
-            cur.append(p)
-            size += p.numel() * 4
-            if size >= bucket_bytes:
-                self.buckets.append(_Bucket(cur, self.device))
-                cur, size = [], 0
-        if cur:
-            self.buckets.append(_Bucket(cur, self.device))
+        self.buckets = [_Bucket(ps, self.device) for ps in plan_buckets(params, bucket_bytes)]
         self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self.exposed_launches = 0
@@ -63,6 +72,15 @@ class BucketedGradReducer:
     # ---- per-gradient hook (runs inside backward) ----------------------------------------------
     def _on_grad(self, p):
         b = self._bucket_of[id(p)]
+        if self.cuda:
+            # The model's modality branches and fusions run on their own streams, and autograd replays each backward node
+            # on the stream of its forward, so the gradients of ONE bucket are written on several streams.  The hook runs
+            # with the stream that produced p.grad current: (re-)record that stream's event; _launch waits for all of them.
+            st = torch.cuda.current_stream(self.device)
+            ent = b.events.get(st.cuda_stream)
+            if ent is None:
+                ent = b.events[st.cuda_stream] = (st, torch.cuda.Event())
+            ent[1].record(st)
         b.pending -= 1
         if b.pending == 0 and not b.launched:
             self._launch(b)
@@ -72,10 +90,16 @@ class BucketedGradReducer:
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
         scale = 1.0 / self.world
         if self.cuda:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))
+            cur = torch.cuda.current_stream(self.device)
+            ent = b.events.get(cur.cuda_stream)        # the zero-filled stand-ins above / a launch from finish() are on `cur`
+            if ent is None:
+                ent = b.events[cur.cuda_stream] = (cur, torch.cuda.Event())
+            ent[1].record(cur)
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ready)
+                for _, ev in b.events.values():        # every stream that wrote one of this bucket's gradients
+                    self.comm_stream.wait_event(ev)
+                for g in grads:                        # allocated on a branch stream, last read here
+                    g.record_stream(self.comm_stream)
                 self._pack(b, grads, scale)
                 b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

@@ -30,8 +30,16 @@ class _ShadowCache:
     def __init__(self):
         self._map = {}
         self.casts = 0
-        self.groups = []    # FlatWeights of live models (weakly referenced through their owner module)
+        self._groups = []   # weakref.ref(FlatWeights): the owner model holds the only strong reference (model._flat)
         self.force = False
+
+    @property
+    def groups(self):
+        """Live FlatWeights groups; a discarded model's group (and its flat fp32/bf16 buffers) dies with the model."""
+        live = [g for g in (r() for r in self._groups) if g is not None]
+        if len(live) != len(self._groups):
+            self._groups = [weakref.ref(g) for g in live]
+        return live
 
     @staticmethod
     def _cast(params):
@@ -73,10 +81,17 @@ class _ShadowCache:
         self.force = True   # flat groups re-cast at their owner's next forward
 
     def attach(self, group):
-        self.groups = [g for g in self.groups if g.intact()] + [group]
+        self._groups = [weakref.ref(g) for g in self.groups if g.intact() and g is not group] + [weakref.ref(group)]
 
     def detach(self, group):
-        self.groups = [g for g in self.groups if g is not group]
+        self._groups = [weakref.ref(g) for g in self.groups if g is not group]
+
+    def drop(self, params):
+        """Forget the cached copies of `params` (FusedAdam rewrites parameters through raw pointers, which does not bump
+        their version counters: without this the GEMMs would keep training against the pre-step bf16 copies)."""
+        ids = {id(p) for p in params}
+        if ids:
+            self._map = {k: v for k, v in self._map.items() if not ids.intersection(k)}
 
 
 class FlatWeights:

@@ -35,22 +35,24 @@ class GraphedStep:
         self.img = img.clone()
         self.labels = labels.clone()
         self._prev_streams = os.environ.get("XVIT_STREAMS")
-        # fork only the self-attention branches inside the capture: with the fusions forked as well, torch 2.10 / ROCm 7.0
-        # segfaults in capture_end (eager mode runs that pattern fine).  XVIT_GRAPH_STREAMS=0 captures on one stream.
-        os.environ["XVIT_STREAMS"] = "0" if os.environ.get("XVIT_GRAPH_STREAMS", "1") == "0" else "branches"
-        side = torch.cuda.Stream(device=img.device)
-        side.wait_stream(torch.cuda.current_stream(img.device))
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self._eager()
-        torch.cuda.current_stream(img.device).wait_stream(side)
-        torch.cuda.synchronize(img.device)
-        self.graph = torch.cuda.CUDAGraph()
-        for p in self.params:
-            p.grad = None                      # gradients are (re)allocated from the graph's private pool
-        with torch.cuda.graph(self.graph):
-            self.logits, self.loss = self._eager(zero=False)
-        self._restore_env()
+        # XVIT_GRAPH_STREAMS: "1" (default) forks the branches AND the fusions inside the capture (parallel graph paths),
+        # "branches" only the self-attention branches, "0" captures everything on one stream.
+        os.environ["XVIT_STREAMS"] = {"0": "0", "branches": "branches"}.get(os.environ.get("XVIT_GRAPH_STREAMS", "1"), "1")
+        try:
+            side = torch.cuda.Stream(device=img.device)
+            side.wait_stream(torch.cuda.current_stream(img.device))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self._eager()
+            torch.cuda.current_stream(img.device).wait_stream(side)
+            torch.cuda.synchronize(img.device)
+            self.graph = torch.cuda.CUDAGraph()
+            for p in self.params:
+                p.grad = None                      # gradients are (re)allocated from the graph's private pool
+            with torch.cuda.graph(self.graph):
+                self.logits, self.loss = self._eager(zero=False)
+        finally:
+            self._restore_env()                    # also when warm-up or capture raises: never leave the process in capture mode
 
     def _restore_env(self):
         if self._prev_streams is None:

@@ -98,3 +98,18 @@ class EpochStatsMixin:
 
     def on_validation_epoch_end(self):
         self._log_epoch_stats("val")
+
+    # ---- test loop surface of both reference models (model_cross.py:294-308, modelv3.py:229-243): logits / targets on the host
+    def on_test_epoch_start(self):
+        self.test_logits = []
+        self.test_targets = []
+
+    def test_step(self, batch, batch_idx):
+        x, labels = batch
+        logits, _ = self(x, labels)
+        self.test_logits.append(logits.detach().cpu())
+        self.test_targets.append(labels.cpu())
+
+    def on_test_epoch_end(self):
+        self.test_logits = torch.cat(self.test_logits)
+        self.test_targets = torch.cat(self.test_targets)

@@ -42,6 +42,11 @@ def _ptr(t) -> int | None:
         return None
     if not t.is_cuda:
         raise RuntimeError("xvit: tensor is not on the GPU; the HIP path has no CPU fallback")
+    if t.device.index != torch.cuda.current_device():
+        # launches go to the CURRENT device's current stream (_stream()): a tensor of another GPU would be written by a
+        # kernel on the wrong device, unordered with torch's own work on the tensor's device
+        raise RuntimeError(f"xvit: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device(...) (one process per GPU) or wrap the call in torch.cuda.device(...)")
     return t.data_ptr()
 
 

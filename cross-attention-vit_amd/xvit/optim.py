@@ -38,7 +38,7 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        touched = set()
+        touched, unshadowed = set(), []
         for group in self.param_groups:
             buckets, keep = {}, []          # step count -> (rows, chunks): torch keeps the step per parameter
             for p in group["params"]:
@@ -58,6 +58,8 @@ class FusedAdam(torch.optim.Optimizer):
                 grp, sh = self._shadow_of(p)
                 if grp is not None:
                     touched.add(id(grp))
+                else:
+                    unshadowed.append(p)
                 keep.append(g)
                 rows, chunks = buckets.setdefault(st["step"], ([], []))
                 t = len(rows)
@@ -76,4 +78,7 @@ class FusedAdam(torch.optim.Optimizer):
         for grp in XF.SHADOWS.groups:
             if id(grp) in touched:
                 grp.stamp = sum(q._version for q in grp.params)
+        # ... and every other parameter (ModelVIT, the model.py Encoder, stand-alone modules, XVIT_FLAT_WEIGHTS=0) only in place:
+        # their per-parameter bf16 copies are keyed by the version counter, which a raw-pointer write does not move
+        XF.SHADOWS.drop(unshadowed)
         return loss

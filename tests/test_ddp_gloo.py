@@ -115,3 +115,31 @@ def test_epoch_statistics_sync_dist_world2(tmp_path):
         assert abs(all0[f"val_{k}"] - ref[k]) < 1e-12, k
     assert all0["val_confusion"]["samples"] == 22 + 29 and all0["val_confusion"]["steps"] == 7
     assert loc0["val_confusion"]["samples"] == 22 and loc1["val_confusion"]["samples"] == 29
+
+
+# ---- bucket plan over the REAL ModelCross parameter list (heads first, shared embedding last) --------
+def test_bucket_order_over_model_cross_parameters():
+    sys.path.insert(0, os.path.join(ROOT, "cross-attention-vit_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_cpu as R
+    import xvit
+    from xvit.ddp import plan_buckets
+    cfg = R.make_config("small")
+    model = xvit.ModelCross(cfg)                       # parameters only: nothing is launched on CPU
+    names = {id(p): k for k, p in model.named_parameters()}
+    plan = plan_buckets(model.parameters(), bucket_bytes=256 << 10)
+    assert len(plan) >= 4
+    flat = [names[id(p)] for b in plan for p in b]
+    assert sorted(flat) == sorted(names.values())      # every parameter in exactly one bucket
+
+    def group(k):
+        if k.startswith(("mlp_head", "norm.")):
+            return 0
+        if k.startswith("transformer."):
+            return 1 + (cfg.num_multi_blocks - 1 - int(k.split(".")[1]))      # last MultiScaleBlock first
+        return 1 + cfg.num_multi_blocks                                        # pos_embedding, patch_to_embedding, cls_token
+
+    order = [group(k) for k in flat]
+    assert order == sorted(order), "gradient buckets must follow backward's readiness order"
+    assert {k.split(".")[0] for k in flat[-4:]} == {"pos_embedding", "patch_to_embedding", "cls_token"}   # the shared embedding comes last
+    assert all(group(names[id(p)]) == 0 for p in plan[0][:4])
