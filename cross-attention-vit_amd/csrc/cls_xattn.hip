@@ -32,9 +32,12 @@ __device__ __forceinline__ float row_dot8(const float (&a)[8], const bf16* mat, 
   return acc;
 }
 
-__global__ __launch_bounds__(XA_THREADS) void cls_xattn_fwd_kernel(const bf16* __restrict__ q, int64_t ldq, const bf16* __restrict__ k,
-                                                                   const bf16* __restrict__ v, int64_t sb, int64_t sn, bf16* __restrict__ o,
-                                                                   int64_t ldo, float* __restrict__ p, int H, int N, float scale, float drop_p,
+// q_f32 / o_f32 (optional): the query in fp32 (used instead of q) and an fp32 copy of the output — the single-token CLS
+// path keeps its operands in fp32 (see linear_f32.hip); o (bf16) is still written for the backward kernel.
+__global__ __launch_bounds__(XA_THREADS) void cls_xattn_fwd_kernel(const bf16* __restrict__ q, int64_t ldq, const float* __restrict__ q_f32, int64_t ldqf,
+                                                                   const bf16* __restrict__ k, const bf16* __restrict__ v, int64_t sb, int64_t sn,
+                                                                   bf16* __restrict__ o, int64_t ldo, float* __restrict__ o_f32, int64_t ldof,
+                                                                   float* __restrict__ p, int H, int N, float scale, float drop_p,
                                                                    uint64_t drop_seed) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* sc = (float*)smem_raw;            // [N] scores -> probabilities
@@ -46,7 +49,11 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_fwd_kernel(const bf16* _
   const bf16* vb = v + (int64_t)b * sb + head * XA_DH;
 
   float qv[8];
-  {
+  if (q_f32) {
+    const float* t = q_f32 + (int64_t)b * ldqf + head * XA_DH + part * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qv[e] = t[e];
+  } else {
     const bf16x8 t = *(const bf16x8*)(q + (int64_t)b * ldq + head * XA_DH + part * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) qv[e] = bf2f(t[e]);
@@ -91,7 +98,8 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_fwd_kernel(const bf16* _
     float r = 0.f;
 #pragma unroll 8
     for (int s = 0; s < 32; ++s) r += part_o[s * 64 + tid];
-    o[(int64_t)b * ldo + head * XA_DH + tid] = f2bf(r);
+    if (o) o[(int64_t)b * ldo + head * XA_DH + tid] = f2bf(r);
+    if (o_f32) o_f32[(int64_t)b * ldof + head * XA_DH + tid] = r;
   }
 }
 
@@ -163,13 +171,14 @@ using namespace xvit;
 
 static size_t xa_lds(int N) { return (size_t)(((N + 3) & ~3) + 4 + 32 * 64) * sizeof(float); }
 
-extern "C" int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t sb, int64_t sn, void* o, int64_t ldo, float* p,
-                                  int B, int H, int N, int dh, float scale, float drop_p, uint64_t drop_seed, xvit_stream_t stream) {
+extern "C" int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const float* q_f32, int64_t ldqf, const void* k, const void* v, int64_t sb, int64_t sn,
+                                  void* o, int64_t ldo, float* o_f32, int64_t ldof, float* p, int B, int H, int N, int dh, float scale, float drop_p,
+                                  uint64_t drop_seed, xvit_stream_t stream) {
   XVIT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "xvit_cls_xattn_fwd: dropout_p must be in [0, 1)");
-  XVIT_REQUIRE(q && k && v && o && p, "xvit_cls_xattn_fwd: null pointer");
+  XVIT_REQUIRE((q || q_f32) && k && v && (o || o_f32) && p, "xvit_cls_xattn_fwd: null pointer");
   XVIT_REQUIRE(dh == XA_DH, "xvit_cls_xattn_fwd: head dim %d unsupported (only 64)", dh);
   XVIT_REQUIRE(B > 0 && H > 0 && N > 0 && B <= 65535, "xvit_cls_xattn_fwd: bad B/H/N");
-  XVIT_REQUIRE(ldq % 8 == 0 && sb % 8 == 0 && sn % 8 == 0, "xvit_cls_xattn_fwd: strides must be multiples of 8 elements");
+  XVIT_REQUIRE((!q || ldq % 8 == 0) && sb % 8 == 0 && sn % 8 == 0, "xvit_cls_xattn_fwd: strides must be multiples of 8 elements");
   XVIT_REQUIRE(xa_lds(N) <= 160 * 1024, "xvit_cls_xattn_fwd: N=%d too long for the LDS score row", N);
   const size_t lds = xa_lds(N);
   static size_t attr = 0;
@@ -177,8 +186,8 @@ extern "C" int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const void* k, con
     (void)hipFuncSetAttribute((const void*)cls_xattn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = lds;
   }
-  hipLaunchKernelGGL(cls_xattn_fwd_kernel, dim3(H, B), dim3(XA_THREADS), lds, (hipStream_t)stream, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, sb,
-                     sn, (bf16*)o, ldo, p, H, N, scale, drop_p, drop_seed);
+  hipLaunchKernelGGL(cls_xattn_fwd_kernel, dim3(H, B), dim3(XA_THREADS), lds, (hipStream_t)stream, (const bf16*)q, ldq, q_f32, ldqf, (const bf16*)k,
+                     (const bf16*)v, sb, sn, (bf16*)o, ldo, o_f32, ldof, p, H, N, scale, drop_p, drop_seed);
   return check_launch("xvit_cls_xattn_fwd");
 }
 

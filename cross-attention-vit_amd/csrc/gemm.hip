@@ -11,7 +11,10 @@
 // Epilogue: accumulators -> wave-private LDS slab -> row-contiguous 16-B accesses.
 #include "xvit_common.h"
 
+#include <atomic>
 #include <mutex>
+#include <algorithm>
+#include <string>
 
 namespace xvit {
 
@@ -25,6 +28,7 @@ struct GemmParams {
   float* slab;          // split-K partial sums [split][batch][M][N], else nullptr
   float* colsum;        // optional [N] fp32: += column sums of the stored C
   float drop_p, drop_inv; uint64_t drop_seed;   // dropout after the activation, before the residual (p == 0: off)
+  int narrow_epi;                // force the 8-byte-per-lane epilogue (A/B measurements)
 };
 
 // ---- the fused epilogue, shared by both tile kernels and the split-K reduce kernel -------------
@@ -523,7 +527,6 @@ __device__ __forceinline__ void big_epilogue(const GemmParams& p, BigEpi& e, con
   EpiLoads first;
   if constexpr (ACT == XVIT_ACT_DGELU) big_epi_issue_aux(p, e, lc, first);
   big_epi_regions<ACT, DROP, 0>(p, e, lc, first, acc, slice, woff, roff);
-#ifndef XVIT_DEBUG_TIMES   // (that build borrows p.colsum as its timestamp buffer)
   if (p.colsum && !e.to_slab) {   // += column sums of the stored tile: lanes l, l+16, l+32, l+48 share their 4 columns
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -537,10 +540,233 @@ __device__ __forceinline__ void big_epilogue(const GemmParams& p, BigEpi& e, con
       for (int c = 0; c < 4; ++c) unsafeAtomicAdd(e.colsum_dst + c, e.csum[c]);
     }
   }
-#endif
 }
 
-template <bool A_KS, bool B_KS>
+// ---- wide epilogue for bf16 outputs: 16 bytes per lane -----------------------------------------------------------
+// With 4 columns per lane a bf16 store (or z load) moves 8 bytes per lane: 64 store instructions per wave tile (128 for
+// the GELU epilogue's z + a), and the epilogue is bound by the ISSUE of those narrow vector-memory instructions, not by
+// HBM (de-phasing the CUs changed nothing; 128 KB per tile in ~6 us = 21 B/clk/CU).  Here a lane owns 8 consecutive
+// columns of one row: 8 lanes cover a 64-column row (128 contiguous bytes), one instruction covers 8 rows, and a wave
+// tile needs 16 stores per bf16 tensor.  Same LDS transpose; the read-back takes two swizzled 16-byte chunks per lane
+// (conflict-free: the XOR keeps an aligned chunk pair together).  Used when C is bf16 with no residual / row remap /
+// split-K slab and N, ldc, ldaux are multiples of 8.
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+struct WideEpi {
+  __amdgpu_buffer_rsrc_t rc, raux;
+  bool has_aux, col_ok;
+  uint32_t col;                  // first of this lane's 8 consecutive output columns
+  f32x4 bias0, bias1, csum0, csum1;
+  uint64_t drop_base;
+  uint32_t row, c, aux, c_step, aux_step;   // the lane's current row, advanced by 8 rows per body
+};
+struct WideCursor { uint32_t row, aux; };
+struct WideLoads { u32x4_t aux[2]; };
+
+__device__ __forceinline__ void wide_issue_aux(const GemmParams& p, const WideEpi& e, WideCursor& lc, WideLoads& L) {
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const bool ok = e.col_ok && lc.row < (uint32_t)p.M;
+    L.aux[b] = __builtin_amdgcn_raw_buffer_load_b128(e.raux, ok ? lc.aux : OOB, 0, 0);
+    lc.row += 8; lc.aux += e.aux_step;
+  }
+}
+
+__device__ __forceinline__ u32x4_t pack_bf16x8(const f32x4& a, const f32x4& b) {
+  const bf16x8 o = {f2bf(a[0]), f2bf(a[1]), f2bf(a[2]), f2bf(a[3]), f2bf(b[0]), f2bf(b[1]), f2bf(b[2]), f2bf(b[3])};
+  return __builtin_bit_cast(u32x4_t, o);
+}
+
+// activation + dropout on 4 of the lane's 8 elements (columns col .. col + 3 of row `row`)
+template <int ACT, bool DROP>
+__device__ __forceinline__ void wide_half(const GemmParams& p, f32x4& v, const bf16x4 z, uint64_t idx) {
+  if (ACT == XVIT_ACT_GELU) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
+  } else if (ACT == XVIT_ACT_DGELU) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] *= dgelu_f(bf2f(z[c]));
+  }
+  if (DROP) {
+    const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = (hash32(p.drop_seed, idx + c) & 0xFFFFFFu) >= thr ? v[c] * p.drop_inv : 0.f;
+  }
+}
+
+template <int ACT, bool DROP>
+__device__ __forceinline__ void wide_body(const GemmParams& p, WideEpi& e, f32x4 v0, f32x4 v1, u32x4_t auxv) {
+  const bool ok = e.col_ok && e.row < (uint32_t)p.M;
+  v0 += e.bias0; v1 += e.bias1;
+  if (ACT == XVIT_ACT_GELU && e.has_aux) __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v0, v1), e.raux, ok ? e.aux : OOB, 0, 0);
+  const bf16x8 z = __builtin_bit_cast(bf16x8, auxv);
+  const uint64_t idx = e.drop_base + (uint64_t)e.row * p.N + e.col;
+  // the two halves one after the other (a scheduling fence between them): eight interleaved GELU / hash evaluations
+  // need more temporaries than the allocator has next to the accumulators still waiting for their LDS pass
+  wide_half<ACT, DROP>(p, v0, bf16x4{z[0], z[1], z[2], z[3]}, idx);
+  if (ACT != XVIT_ACT_NONE || DROP) __builtin_amdgcn_sched_barrier(0);
+  wide_half<ACT, DROP>(p, v1, bf16x4{z[4], z[5], z[6], z[7]}, idx + 4);
+  __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v0, v1), e.rc, ok ? e.c : OOB, 0, 0);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { e.csum0[c] += ok ? v0[c] : 0.f; e.csum1[c] += ok ? v1[c] : 0.f; }
+  e.row += 8; e.c += e.c_step; e.aux += e.aux_step;
+}
+
+// Region R (0..7) = 2 bodies = rows 16 R .. 16 R + 15 of the wave tile (one scheduling window: with 4 bodies of 8 elements
+// in one window the allocator spills); regions 0-3 and 4-7 share one LDS transpose pass.
+template <int ACT, bool DROP, int R>
+__device__ __forceinline__ void wide_regions(const GemmParams& p, WideEpi& e, WideCursor& lc, WideLoads& cur, const f32x4 (&acc)[8][4], XVIT_LDS char* slice,
+                                             const uint32_t (&woff)[4], const uint32_t (&roffw)[2][2]) {
+  if constexpr ((R & 3) == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *(XVIT_LDS f32x4*)(slice + i * 4096 + woff[j]) = acc[(R >> 2) * 4 + i][j];
+  }
+  WideLoads nxt;
+  if constexpr (ACT == XVIT_ACT_DGELU && R < 7) wide_issue_aux(p, e, lc, nxt);
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int it = (R & 3) * 2 + b;   // 8-row group inside the 64-row pass
+    const f32x4 v0 = *(const XVIT_LDS f32x4*)(slice + it * 2048 + roffw[it & 1][0]);
+    const f32x4 v1 = *(const XVIT_LDS f32x4*)(slice + it * 2048 + roffw[it & 1][1]);
+    wide_body<ACT, DROP>(p, e, v0, v1, cur.aux[b]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (R < 7) wide_regions<ACT, DROP, R + 1>(p, e, lc, nxt, acc, slice, woff, roffw);
+}
+
+template <int ACT, bool DROP>
+__device__ __forceinline__ void wide_epilogue(const GemmParams& p, WideEpi& e, const f32x4 (&acc)[8][4], XVIT_LDS char* slice, const uint32_t (&woff)[4],
+                                              const uint32_t (&roffw)[2][2], float* colsum_dst) {
+  WideCursor lc = {e.row, e.aux};
+  WideLoads first;
+  if constexpr (ACT == XVIT_ACT_DGELU) wide_issue_aux(p, e, lc, first);
+  wide_regions<ACT, DROP, 0>(p, e, lc, first, acc, slice, woff, roffw);
+  if (colsum_dst) {   // lanes l, l+8, ..., l+56 share their 8 columns
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float t0 = e.csum0[c], t1 = e.csum1[c];
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { t0 += __shfl_xor(t0, o); t1 += __shfl_xor(t1, o); }
+      e.csum0[c] = t0; e.csum1[c] = t1;
+    }
+    if ((threadIdx.x & 63) < 8 && e.col_ok) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { unsafeAtomicAdd(colsum_dst + c, e.csum0[c]); unsafeAtomicAdd(colsum_dst + 4 + c, e.csum1[c]); }
+    }
+  }
+}
+
+template <int ACT>
+__device__ __forceinline__ void wave_tile_epilogue_wide(const GemmParams& p, const f32x4 (&acc)[8][4], XVIT_LDS char* smem, int wave, int lane, int row0, int col0,
+                                                        int batch) {
+  WideEpi e;
+  e.rc = make_rsrc((const char*)p.C + batch * p.sC * 2, clamp_bytes(0x7FFFFFF0ll));
+  e.has_aux = p.aux != nullptr;
+  const bool has_bias = p.bias != nullptr;
+  e.raux = make_rsrc(e.has_aux ? (const void*)(p.aux + batch * p.sAux) : (const void*)p.C, e.has_aux ? 0x7FFFFFF0u : 0u);
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(has_bias ? (const void*)(p.bias + batch * p.sBias) : (const void*)p.C, has_bias ? (uint32_t)(p.N * 4) : 0u);
+  int pin = 0;                       // keep the address arithmetic below the K loop (see wave_tile_epilogue)
+  asm volatile("" : "+v"(pin));
+  const int wl = lane + pin;
+  uint32_t woff[4], roffw[2][2];
+  {
+    const int r = wl & 15, g = wl >> 4, c = wl & 7, rr = wl >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = (uint32_t)(r * 256 + (((j * 4 + g) ^ r) << 4));
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) roffw[par][k] = (uint32_t)(rr * 256 + (((2 * c + k) ^ ((par * 8 + rr) & 15)) << 4));
+  }
+  XVIT_LDS char* slice = smem + wave * EPI_WAVE_BYTES;
+  e.col = (uint32_t)(col0 + (wl & 7) * 8);
+  e.col_ok = e.col < (uint32_t)p.N;
+  e.bias0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, e.col * 4, 0, 0));
+  e.bias1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, e.col * 4 + 16, 0, 0));
+  e.drop_base = (uint64_t)batch * ((uint64_t)p.M * p.N);
+  e.csum0 = f32x4{0.f, 0.f, 0.f, 0.f}; e.csum1 = f32x4{0.f, 0.f, 0.f, 0.f};
+  float* colsum_dst = p.colsum ? p.colsum + batch * p.sBias + e.col : nullptr;
+  e.row = (uint32_t)(row0 + (wl >> 3));
+  e.c = e.row * (uint32_t)p.ldc * 2u + e.col * 2u;
+  e.aux = e.row * (uint32_t)p.ldaux * 2u + e.col * 2u;
+  e.c_step = 8u * (uint32_t)p.ldc * 2u;
+  e.aux_step = 8u * (uint32_t)p.ldaux * 2u;
+  wide_epilogue<ACT, false>(p, e, acc, slice, woff, roffw, colsum_dst);
+}
+
+// Epilogue of one wave's 128 x 64 accumulator tile whose first element is (row0, col0); shared by every tile kernel
+// (the block's stage buffers are idle by now: wave w bounces through smem + w * EPI_WAVE_BYTES).
+__device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, const f32x4 (&acc)[8][4], XVIT_LDS char* smem, int wave, int lane, int row0, int col0,
+                                                   int batch, int split) {
+  const int nbatch = gridDim.z / p.split_k;
+  BigEpi e;
+  const int64_t celt = p.c_f32 ? 4 : 2;
+  e.rc = make_rsrc((const char*)p.C + batch * p.sC * celt, clamp_bytes(0x7FFFFFF0ll));
+  e.has_aux = p.aux != nullptr; e.has_res = p.res != nullptr; e.to_slab = p.slab != nullptr;
+  const bool has_bias = p.bias != nullptr;
+  e.raux = make_rsrc(e.has_aux ? (const void*)(p.aux + batch * p.sAux) : (const void*)p.C, e.has_aux ? 0x7FFFFFF0u : 0u);
+  e.rres = make_rsrc(e.has_res ? (const void*)(p.res + batch * p.sR) : (const void*)p.C, e.has_res ? 0x7FFFFFF0u : 0u);
+  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(has_bias ? (const void*)(p.bias + batch * p.sBias) : (const void*)p.C, has_bias ? (uint32_t)(p.N * 4) : 0u);
+  e.rslab = make_rsrc(e.to_slab ? (const void*)(p.slab + ((int64_t)split * nbatch + batch) * (int64_t)p.M * p.N) : (const void*)p.C,
+                      e.to_slab ? clamp_bytes((int64_t)p.M * p.N * 4) : 0u);
+  // the epilogue's address arithmetic is loop-invariant: without this opaque dependency (placed AFTER the K loop)
+  // LLVM hoists it above the MFMA loop and spills the accumulators
+  int pin = 0;
+  asm volatile("" : "+v"(pin));
+  const int wl = lane + pin;
+  // LDS slice offsets: accumulator layout (row r = lane & 15 of each 16-row tile, chunk 4 J + g) and read-back
+  // layout (row 4 it + rr, chunk k), both with chunk ^= row & 15
+  uint32_t woff[4], roff[4];
+  {
+    const int r = wl & 15, g = wl >> 4, k = wl & 15, rr = wl >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) woff[j] = (uint32_t)(r * 256 + (((j * 4 + g) ^ r) << 4));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) roff[q] = (uint32_t)(rr * 256 + ((k ^ (q * 4 + rr)) << 4));
+  }
+  XVIT_LDS char* slice = smem + wave * EPI_WAVE_BYTES;
+  e.col = (uint32_t)(col0 + (wl & 15) * 4);
+  e.col_ok = e.col < (uint32_t)p.N;
+  e.bias = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, e.col * 4, 0, 0));   // zero-size descriptor when there is no bias
+  e.drop_base = (uint64_t)batch * ((uint64_t)p.M * p.N);
+  e.csum = f32x4{0.f, 0.f, 0.f, 0.f};
+  e.colsum_dst = p.colsum ? p.colsum + batch * p.sBias + e.col : nullptr;
+  e.row = (uint32_t)(row0 + (wl >> 4));
+  {
+    const bool rmap = p.res_row_mod > 0, smap = p.seg_rows > 0;
+    e.rmod = rmap ? (uint32_t)p.res_row_mod : 0x7FFFFFFFu;
+    e.smod = smap ? (uint32_t)p.seg_rows : 0x7FFFFFFFu;
+    e.rrem = rmap ? e.row % e.rmod : e.row;
+    e.srem = smap ? e.row % e.smod : e.row;
+    const uint32_t rrow = rmap ? (uint32_t)p.res_row_off + e.rrem : e.row;
+    const uint32_t orow = smap ? e.row + (e.row / e.smod) * (uint32_t)p.seg_skip + (uint32_t)p.row_off : e.row;
+    const uint32_t ce = p.c_f32 ? 4u : 2u;
+    e.c = orow * (uint32_t)p.ldc * ce + e.col * ce;
+    e.aux = e.row * (uint32_t)p.ldaux * 2u + e.col * 2u;
+    e.res = rrow * (uint32_t)p.ldr * 4u + e.col * 4u;
+    e.slab = e.row * (uint32_t)p.N * 4u + e.col * 4u;
+    e.c_step = 4u * (uint32_t)p.ldc * ce;
+    e.aux_step = 4u * (uint32_t)p.ldaux * 2u;
+    e.res_step = 4u * (uint32_t)p.ldr * 4u;
+    e.slab_step = 4u * (uint32_t)p.N * 4u;
+    e.c_gap = smap ? (uint32_t)p.seg_skip * (uint32_t)p.ldc * ce : 0u;
+    e.res_wrap = rmap ? e.rmod * (uint32_t)p.ldr * 4u : 0u;
+  }
+  // one specialised, fully unrolled copy per (activation, dropout): every acc[][] index is a compile-time constant
+  if (p.drop_p > 0.f) {
+    if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, true>(p, e, acc, slice, woff, roff);
+    else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, true>(p, e, acc, slice, woff, roff);
+    else big_epilogue<XVIT_ACT_NONE, true>(p, e, acc, slice, woff, roff);
+  } else if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, false>(p, e, acc, slice, woff, roff);
+  else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, false>(p, e, acc, slice, woff, roff);
+  else big_epilogue<XVIT_ACT_NONE, false>(p, e, acc, slice, woff, roff);
+}
+
+// WIDE_ACT >= 0: the 16-byte-per-lane bf16 epilogue with that activation and no dropout, as its own instantiation (with
+// several fully unrolled epilogue variants behind one K loop the register allocator spills: one variant per kernel here;
+// the narrow kernels keep the run-time switch over activation x dropout and do not spill).  WIDE_ACT = -1: narrow.
+template <bool A_KS, bool B_KS, int WIDE_ACT>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
@@ -563,11 +789,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int nk = (k_end - k_begin + BK - 1) / BK;   // may be 0 for a trailing split: still writes its (zero) slab
 
-#ifdef XVIT_DEBUG_TIMES
-  uint64_t tstamp[5];
-  tstamp[0] = wall_clock64(); tstamp[1] = 0;
-  uint64_t itv[3] = {0, 0, 0}, itprev = 0;
-#endif
   BigLoader<A_KS> la;
   BigLoader<B_KS> lb;
   {
@@ -597,116 +818,20 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#ifdef XVIT_DEBUG_TIMES
-    if (kt == 0) tstamp[1] = wall_clock64();
-    uint64_t it0 = __builtin_readcyclecounter();
-#endif
     const bool more = kt + 1 < nk;
     XVIT_LDS char* nxt = smem + ((kt + 1) & 1) * T_STAGE;
     const XVIT_LDS char* sa = smem + (kt & 1) * T_STAGE;
     const XVIT_LDS char* sb = sa + T_OPER;
-#ifdef XVIT_DEBUG_TIMES
-    uint64_t it1 = __builtin_readcyclecounter();
-#endif
 #ifndef XVIT_DEBUG_NO_MMA
     big_tile_mma<A_KS, B_KS>(sa, sb, fa, fb, acc, la, lb, more ? la.rsrc : null_rsrc, more ? lb.rsrc : null_rsrc, nxt, wave,
                              (uint32_t)(kt + 1) * la.kstep, (uint32_t)(kt + 1) * lb.kstep);
 #endif
-#ifdef XVIT_DEBUG_TIMES
-    if (kt == 4) { itv[0] = it1 - it0; itv[1] = __builtin_readcyclecounter() - it1; }
-    if (kt == 5) { itv[2] = it0 - itprev; }
-    itprev = __builtin_readcyclecounter();
-#endif
   }
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last iteration's (zero-fill) DMAs have landed before the stage buffers are recycled
-  // ---------------- epilogue: per-wave LDS transpose, then row-contiguous global accesses ---------------
-#ifdef XVIT_DEBUG_TIMES
-  tstamp[2] = wall_clock64();
-#endif
   __syncthreads();   // every wave is done reading the last stage: the stage buffers become the transpose slices
-  const int nbatch = gridDim.z / p.split_k;
-  BigEpi e;
-  const int64_t celt = p.c_f32 ? 4 : 2;
-  e.rc = make_rsrc((const char*)p.C + batch * p.sC * celt, clamp_bytes(0x7FFFFFF0ll));
-  e.has_aux = p.aux != nullptr; e.has_res = p.res != nullptr; e.to_slab = p.slab != nullptr;
-  const bool has_bias = p.bias != nullptr;
-  e.raux = make_rsrc(e.has_aux ? (const void*)(p.aux + batch * p.sAux) : (const void*)p.C, e.has_aux ? 0x7FFFFFF0u : 0u);
-  e.rres = make_rsrc(e.has_res ? (const void*)(p.res + batch * p.sR) : (const void*)p.C, e.has_res ? 0x7FFFFFF0u : 0u);
-  const __amdgpu_buffer_rsrc_t rbias = make_rsrc(has_bias ? (const void*)(p.bias + batch * p.sBias) : (const void*)p.C, has_bias ? (uint32_t)(p.N * 4) : 0u);
-  e.rslab = make_rsrc(e.to_slab ? (const void*)(p.slab + ((int64_t)split * nbatch + batch) * (int64_t)p.M * p.N) : (const void*)p.C,
-                      e.to_slab ? clamp_bytes((int64_t)p.M * p.N * 4) : 0u);
-  // the epilogue's address arithmetic is loop-invariant: without this opaque dependency (placed AFTER the K loop)
-  // LLVM hoists it above the MFMA loop and spills the accumulators
-  int pin = 0;
-  asm volatile("" : "+v"(pin));
-  const int wl = lane + pin;
-  // LDS slice offsets: accumulator layout (row r = lane & 15 of each 16-row tile, chunk 4 J + g) and read-back
-  // layout (row 4 it + rr, chunk k), both with chunk ^= row & 15
-  uint32_t woff[4], roff[4];
-  {
-    const int r = wl & 15, g = wl >> 4, k = wl & 15, rr = wl >> 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) woff[j] = (uint32_t)(r * 256 + (((j * 4 + g) ^ r) << 4));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) roff[q] = (uint32_t)(rr * 256 + ((k ^ (q * 4 + rr)) << 4));
-  }
-  XVIT_LDS char* slice = smem + wave * EPI_WAVE_BYTES;
-  e.col = (uint32_t)(n0 + wc * 64 + (wl & 15) * 4);
-  e.col_ok = e.col < (uint32_t)p.N;
-#ifdef XVIT_DEBUG_NOSTORE
-  e.col_ok = e.col_ok && pin != 0;
-#endif
-  e.bias = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, e.col * 4, 0, 0));   // zero-size descriptor when there is no bias
-  e.drop_base = (uint64_t)batch * ((uint64_t)p.M * p.N);
-  e.csum = f32x4{0.f, 0.f, 0.f, 0.f};
-  e.colsum_dst = p.colsum ? p.colsum + batch * p.sBias + e.col : nullptr;
-  e.row = (uint32_t)(m0 + wr * 128 + (wl >> 4));
-  {
-    const bool rmap = p.res_row_mod > 0, smap = p.seg_rows > 0;
-    e.rmod = rmap ? (uint32_t)p.res_row_mod : 0x7FFFFFFFu;
-    e.smod = smap ? (uint32_t)p.seg_rows : 0x7FFFFFFFu;
-    e.rrem = rmap ? e.row % e.rmod : e.row;
-    e.srem = smap ? e.row % e.smod : e.row;
-    const uint32_t rrow = rmap ? (uint32_t)p.res_row_off + e.rrem : e.row;
-    const uint32_t orow = smap ? e.row + (e.row / e.smod) * (uint32_t)p.seg_skip + (uint32_t)p.row_off : e.row;
-    const uint32_t ce = p.c_f32 ? 4u : 2u;
-    e.c = orow * (uint32_t)p.ldc * ce + e.col * ce;
-    e.aux = e.row * (uint32_t)p.ldaux * 2u + e.col * 2u;
-    e.res = rrow * (uint32_t)p.ldr * 4u + e.col * 4u;
-    e.slab = e.row * (uint32_t)p.N * 4u + e.col * 4u;
-    e.c_step = 4u * (uint32_t)p.ldc * ce;
-    e.aux_step = 4u * (uint32_t)p.ldaux * 2u;
-    e.res_step = 4u * (uint32_t)p.ldr * 4u;
-    e.slab_step = 4u * (uint32_t)p.N * 4u;
-    e.c_gap = smap ? (uint32_t)p.seg_skip * (uint32_t)p.ldc * ce : 0u;
-    e.res_wrap = rmap ? e.rmod * (uint32_t)p.ldr * 4u : 0u;
-  }
-#ifdef XVIT_DEBUG_TIMES
-  tstamp[3] = wall_clock64();
-#endif
-  // one specialised, fully unrolled copy per (activation, dropout): every acc[][] index is a compile-time constant
-  if (p.drop_p > 0.f) {
-    if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, true>(p, e, acc, slice, woff, roff);
-    else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, true>(p, e, acc, slice, woff, roff);
-    else big_epilogue<XVIT_ACT_NONE, true>(p, e, acc, slice, woff, roff);
-  } else if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, false>(p, e, acc, slice, woff, roff);
-  else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, false>(p, e, acc, slice, woff, roff);
-  else big_epilogue<XVIT_ACT_NONE, false>(p, e, acc, slice, woff, roff);
-#ifdef XVIT_DEBUG_TIMES
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  tstamp[4] = wall_clock64();
-  if (p.colsum && threadIdx.x == 0) {
-    uint64_t* dst = (uint64_t*)p.colsum + (size_t)blockIdx.x * 8;
-    for (int i = 0; i < 5; ++i) dst[i] = tstamp[i];
-    dst[5] = __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 4 /*HW_ID*/ );   // wave/simd/cu/se ids
-    dst[6] = wall_clock64();
-  }
-  if (p.colsum && lane == 0) {   // per-wave: cycles spent issuing the DMAs, in the MFMA section, and waiting at the top (iteration 4 -> 5)
-    uint64_t* dw = (uint64_t*)p.colsum + (size_t)gridDim.x * 8 + ((size_t)blockIdx.x * 8 + wave) * 4;
-    dw[0] = itv[0]; dw[1] = itv[1]; dw[2] = itv[2];
-  }
-#endif
+  if constexpr (WIDE_ACT >= 0) wave_tile_epilogue_wide<WIDE_ACT>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, batch);
+  else wave_tile_epilogue(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, batch, split);
 }
 
 // split-K second pass: sum the partial tiles in a fixed order (bit-reproducible), then the full epilogue
@@ -737,10 +862,22 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // 256x256 tiles (one block per CU, 128 FLOP per staged byte) unless their grid would occupy at most half of the
 // 256 CUs: then the 128x128 kernel (4x the blocks, two per CU) finishes sooner despite its lower intensity
 // (e.g. the reference's batch 8: M = 4104 rows -> 17 x 3 big tiles for a d-wide GEMM).
+static std::atomic<int> g_gemm_tile{0};      // xvit_set_option("gemm_tile"): 0 = auto, 1 = always the 128x128 kernel
+static std::atomic<int> g_gemm_epi{0};       // xvit_set_option("gemm_epilogue"): 0 = auto, 1 = always the 8-byte-per-lane epilogue
+
 static bool use_big_tile(const xvit_gemm_args* a) {
-  if (a->M < 256 || a->N < 256) return false;
+  if (a->M < 256 || a->N < 256 || g_gemm_tile.load(std::memory_order_relaxed) == 1) return false;
   const int64_t big_blocks = (int64_t)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->batch * (a->split_k > 0 ? a->split_k : 1);
   return big_blocks > 128;
+}
+
+extern "C" int xvit_set_option(const char* name, int value) {
+  XVIT_REQUIRE(name != nullptr, "xvit_set_option: null name");
+  const std::string n(name);
+  if (n == "gemm_tile") { XVIT_REQUIRE(value == 0 || value == 1, "xvit_set_option: gemm_tile must be 0 (auto) or 1 (128x128 only)"); g_gemm_tile = value; return 0; }
+  if (n == "gemm_epilogue") { XVIT_REQUIRE(value == 0 || value == 1, "xvit_set_option: gemm_epilogue must be 0 (auto) or 1 (narrow)"); g_gemm_epi = value; return 0; }
+  set_error("xvit_set_option: unknown option '%s'", name);
+  return XVIT_ERR_ARG;
 }
 
 extern "C" int64_t xvit_gemm_workspace_bytes(const xvit_gemm_args* a) {
@@ -796,6 +933,7 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   p.colsum = a->colsum;
   XVIT_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "xvit_gemm: dropout_p must be in [0, 1)");
   p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
+  p.narrow_epi = g_gemm_epi.load(std::memory_order_relaxed);
   hipStream_t s = (hipStream_t)stream;
 
   static std::once_flag attr_once;   // the library is re-entrant: concurrent first calls from several host threads
@@ -803,18 +941,28 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, -1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, XVIT_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, XVIT_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, XVIT_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, XVIT_ACT_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
   });
   if (big) {
     p.ntm = (a->M + TBM - 1) / TBM; p.ntn = (a->N + TBN - 1) / TBN;
     const dim3 grid(p.ntm * p.ntn, 1, a->batch * a->split_k), block(512);
-    switch (a->layout) {
-      case XVIT_GEMM_NT: hipLaunchKernelGGL((gemm_big_kernel<false, false>), grid, block, T_LDS, s, p); break;
-      case XVIT_GEMM_NN: hipLaunchKernelGGL((gemm_big_kernel<false, true>), grid, block, T_LDS, s, p); break;
-      default: hipLaunchKernelGGL((gemm_big_kernel<true, true>), grid, block, T_LDS, s, p); break;
-    }
+    // bf16 C with nothing but bias / activation / column sums behind it: the 16-byte-per-lane epilogue (forward Linears use
+    // NONE or GELU, dgrads NONE or GELU'; wgrads store fp32; with dropout the narrow kernels run)
+    const bool wide = !p.c_f32 && !p.slab && !p.res && p.seg_rows == 0 && !p.narrow_epi && p.drop_p == 0.f && a->layout != XVIT_GEMM_TN &&
+                      ((p.N | (int)p.ldc | (int)p.ldaux) & 7) == 0 && (a->layout == XVIT_GEMM_NT ? p.act != XVIT_ACT_DGELU : p.act != XVIT_ACT_GELU);
+    if (wide && a->layout == XVIT_GEMM_NT && p.act == XVIT_ACT_NONE) hipLaunchKernelGGL((gemm_big_kernel<false, false, XVIT_ACT_NONE>), grid, block, T_LDS, s, p);
+    else if (wide && a->layout == XVIT_GEMM_NT) hipLaunchKernelGGL((gemm_big_kernel<false, false, XVIT_ACT_GELU>), grid, block, T_LDS, s, p);
+    else if (wide && p.act == XVIT_ACT_NONE) hipLaunchKernelGGL((gemm_big_kernel<false, true, XVIT_ACT_NONE>), grid, block, T_LDS, s, p);
+    else if (wide) hipLaunchKernelGGL((gemm_big_kernel<false, true, XVIT_ACT_DGELU>), grid, block, T_LDS, s, p);
+    else if (a->layout == XVIT_GEMM_NT) hipLaunchKernelGGL((gemm_big_kernel<false, false, -1>), grid, block, T_LDS, s, p);
+    else if (a->layout == XVIT_GEMM_NN) hipLaunchKernelGGL((gemm_big_kernel<false, true, -1>), grid, block, T_LDS, s, p);
+    else hipLaunchKernelGGL((gemm_big_kernel<true, true, -1>), grid, block, T_LDS, s, p);
   } else {
     p.ntm = (a->M + BM - 1) / BM; p.ntn = (a->N + BN - 1) / BN;
     const dim3 grid(p.ntm * p.ntn, 1, a->batch * a->split_k), block(256);

@@ -13,8 +13,8 @@ constexpr int LNB_WAVES = 4;   // backward: 4-wave blocks, [4][2][d] LDS reducti
 template <int V>  // V float4 per lane: d <= 256*V
 __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x_alt, int64_t ldx,
                                                                int seq_len, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               float eps, bf16* __restrict__ y, int64_t ldy, float* __restrict__ mean,
-                                                               float* __restrict__ rstd, int rows, int d) {
+                                                               float eps, bf16* __restrict__ y, int64_t ldy, float* __restrict__ yf, int64_t ldyf,
+                                                               float* __restrict__ mean, float* __restrict__ rstd, int rows, int d) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d >> 2;  // float4 per row
   const float inv_d = 1.0f / (float)d;
@@ -41,16 +41,19 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const float* __re
     }
     const float rs = rsqrtf(wave_sum(ss) * inv_d + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-    bf16* yr = y + (int64_t)row * ldy;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const int c = lane + i * 64;
       if (c < nv) {
         const f32x4 g = ((const f32x4*)gamma)[c], b = ((const f32x4*)beta)[c];
-        bf16x4 o;
+        f32x4 of;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = f2bf((v[i][e] - mu) * rs * g[e] + b[e]);
-        *(bf16x4*)(yr + c * 4) = o;
+        for (int e = 0; e < 4; ++e) of[e] = (v[i][e] - mu) * rs * g[e] + b[e];
+        if (y) {
+          bf16x4 o = {f2bf(of[0]), f2bf(of[1]), f2bf(of[2]), f2bf(of[3])};
+          *(bf16x4*)(y + (int64_t)row * ldy + c * 4) = o;
+        }
+        if (yf) *(f32x4*)(yf + (int64_t)row * ldyf + c * 4) = of;   // the single-token CLS path keeps its operands in fp32
       }
     }
   }
@@ -165,17 +168,19 @@ static int ln_grid(int rows) {
 }
 
 extern "C" int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_len, const float* gamma, const float* beta,
-                                  float eps, void* y, int64_t ldy, float* mean, float* rstd, int rows, int d, xvit_stream_t stream) {
-  XVIT_REQUIRE(x && gamma && beta && y && mean && rstd, "xvit_layernorm_fwd: null pointer");
+                                  float eps, void* y, int64_t ldy, float* y_f32, int64_t ldyf, float* mean, float* rstd, int rows, int d,
+                                  xvit_stream_t stream) {
+  XVIT_REQUIRE(x && gamma && beta && (y || y_f32) && mean && rstd, "xvit_layernorm_fwd: null pointer");
+  XVIT_REQUIRE(!y_f32 || (ldyf % 4 == 0 && ldyf >= d), "xvit_layernorm_fwd: ldyf must be a multiple of 4 and >= d");
   XVIT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 4096, "xvit_layernorm_fwd: need 0 < d <= 4096, d %% 4 == 0 (d=%d rows=%d)", d, rows);
   XVIT_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d, "xvit_layernorm_fwd: ldx/ldy must be multiples of 4 and >= d");
   XVIT_REQUIRE(!x_alt || seq_len > 0, "xvit_layernorm_fwd: x_alt needs seq_len > 0");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ln_grid(rows)), block(LN_WAVES * 64);
   bf16* yb = (bf16*)y;
-  if (d <= 768) hipLaunchKernelGGL((ln_fwd_kernel<3>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, mean, rstd, rows, d);
-  else if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, mean, rstd, rows, d);
-  else hipLaunchKernelGGL((ln_fwd_kernel<16>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, mean, rstd, rows, d);
+  if (d <= 768) hipLaunchKernelGGL((ln_fwd_kernel<3>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, y_f32, ldyf, mean, rstd, rows, d);
+  else if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, y_f32, ldyf, mean, rstd, rows, d);
+  else hipLaunchKernelGGL((ln_fwd_kernel<16>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, y_f32, ldyf, mean, rstd, rows, d);
   return check_launch("xvit_layernorm_fwd");
 }
 

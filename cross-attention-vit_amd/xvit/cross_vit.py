@@ -148,12 +148,35 @@ class CrossAttentionBlock(nn.Module):
         return XF.CrossFusionFn.apply(x, x, *_fusion_args(self), False, _p(self, self.attn.fn.attn_drop))
 
 
+class _FanOut(torch.autograd.Function):
+    """x -> n aliases of x whose gradients are summed HERE, on this node's stream.  A tensor consumed by nodes on different
+    side streams otherwise has its gradients accumulated inside the autograd engine's input buffer, across streams (the
+    engine's own event hand-off); under HIP-graph capture that cross-stream accumulation is what crashed
+    hipStreamEndCapture.  With one gradient slot per consumer the engine only orders each producer stream before this
+    node — the pattern the branch fork already uses."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        total = gs[0]
+        for g in gs[1:]:
+            total = total + g
+        return total, None
+
+
 _SIDE_STREAMS: dict = {}
 
 
-def _side_streams(device, n):
-    """Per-device pool of side streams for the modality branches / fusions (shared by every model in the process)."""
-    key = (device, n)
+def _side_streams(device, n, kind="branches"):
+    """Per-device pool of side streams for the modality branches / fusions (shared by every model in the process).
+    XVIT_STREAM_POOLS=split gives the fusions their own streams instead of re-forking the branch streams."""
+    key = (device, n, kind if os.environ.get("XVIT_STREAM_POOLS", "shared") == "split" else "")
     if key not in _SIDE_STREAMS:
         if os.environ.get("XVIT_CU_SPLIT", "0") == "1":   # each branch owns 1/n of the CUs (see xvit/cu_mask.py)
             from . import cu_mask
@@ -189,7 +212,7 @@ class MultiScaleBlock(nn.Module):
             return outs
         dev = tensors[0].device
         cur = torch.cuda.current_stream(dev)
-        streams = _side_streams(dev, len(thunks))
+        streams = _side_streams(dev, len(thunks), kind)
         # While a HIP graph is being captured every tensor lives in the graph's private pool and the order of the replayed
         # work is fixed by the captured fork/join edges: record_stream (an allocator hint for eager reuse) has nothing to
         # protect there, and its deferred-event bookkeeping on pool blocks is what capture_end tripped over.
@@ -216,6 +239,19 @@ class MultiScaleBlock(nn.Module):
         """cls_only (used by ModelCross for its last block, whose outputs are read through their CLS rows only): the
         fusions return [B, 1, d] instead of re-attaching the new CLS token to a copy of the patch tokens."""
         attn = self._branches(x)
+        # every reader of a branch output (its own fusion, other fusions that take its patch tokens, the pass-through) gets
+        # its own alias, so the gradients are summed by _FanOut instead of across streams inside the engine
+        M = len(self.blocks)
+        readers = [[("own", i)] if str(i) in self.attn_order else [("pass", i)] for i in range(M)]
+        for k, v in self.attn_order.items():
+            if int(v) != int(k):
+                readers[int(v)].append(("tok", int(k)))
+        alias = {}
+        for i, a in enumerate(attn):
+            fan = len(readers[i]) > 1 and a.is_cuda and a.requires_grad and os.environ.get("XVIT_FANOUT", "1") == "1"
+            outs_i = _FanOut.apply(a, len(readers[i])) if fan else [a] * len(readers[i])
+            for r, t in zip(readers[i], outs_i):
+                alias[(i,) + r] = t
         thunks = []
         cross_count = 0
         for i in range(len(self.blocks)):
@@ -223,12 +259,14 @@ class MultiScaleBlock(nn.Module):
                 j = int(self.attn_order[str(i)])
                 blk = self.fusion[cross_count]
                 # cls of i + patch tokens of j -> new cls, re-attached to i's own patch tokens (:140-142)
-                thunks.append(lambda i=i, j=j, blk=blk: XF.CrossFusionFn.apply(attn[i], attn[j], *_fusion_args(blk), not cls_only, _p(blk, blk.attn.fn.attn_drop)))
+                xi = alias[(i, "own", i)]
+                xj = xi if j == i else alias[(j, "tok", i)]
+                thunks.append(lambda xi=xi, xj=xj, blk=blk: XF.CrossFusionFn.apply(xi, xj, *_fusion_args(blk), not cls_only, _p(blk, blk.attn.fn.attn_drop)))
                 cross_count += 1
             else:
                 thunks.append(None)                                    # no fusion for this modality: its tokens pass through (:146)
         outs = self._parallel(thunks, list(attn), kind="fusion")   # the fusions only read the branch outputs: independent of each other
-        return [attn[i] if o is None else o for i, o in enumerate(outs)]
+        return [alias[(i, "pass", i)] if o is None else o for i, o in enumerate(outs)]
 
 
 class ModelCross(EpochStatsMixin, _Base):

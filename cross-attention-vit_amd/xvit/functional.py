@@ -380,23 +380,29 @@ class EncoderBlockFn(Function):
 # ------------------------------------------------------------------------------------------
 
 
-def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq_s, bq, wkv_s, bkv, wp_s, bp, ln2w, ln2b, w1_s, b1, w2_s, b2, p=0.0, seeds=(0, 0, 0, 0)):
-    """xi, xj fp32 [B*N, d] (cls taken from xi, patch tokens from xj) -> (y2 fp32 [B, d], saved)."""
+def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq, bq, wkv_s, bkv, wp, bp, ln2w, ln2b, w1, b1, w2, b2, p=0.0, seeds=(0, 0, 0, 0)):
+    """xi, xj fp32 [B*N, d] (cls taken from xi, patch tokens from xj) -> (y2 fp32 [B, d], saved).
+
+    Two precisions on purpose.  The key/value projection runs over all N tokens: bf16 operands on the MFMA tile kernels
+    (wkv_s = bf16 copy of wk|wv).  Everything downstream of the CLS query is ONE row per sample — wq, the attention
+    output, proj, LayerNorm, the FFN (wq, wp, w1, w2 = the fp32 master weights) — and runs fp32 operands
+    (xvit_linear_f32): that row feeds 2 small logits through ~10 stages with nothing to average bf16 storage rounding
+    over, which cost 5e-3 on the CLS rows and ~2e-2 on the logits for <0.1 % of the FLOPs.  bf16 copies of the
+    activations are emitted alongside for the backward chain (unchanged: bf16 operands, fp32 accumulation)."""
     d = xi.shape[1]
     scale = (d // H) ** -0.5
     hn, mu, rs = ops.layernorm_fwd(xj, ln1w, ln1b, eps, x_alt=xi, seq_len=N)
     kv = _linear(hn, wkv_s, bias=bkv)
-    hn0 = hn.reshape(B, N * d)[:, :d]                      # the B normed CLS rows, ld = N*d
-    q = _linear(hn0, wq_s, bias=bq)
+    cls_in = xi.reshape(B, N * d)[:, :d]                   # un-normed CLS rows (row 0 of the concat; the residual, :112), ld = N*d
+    hn0f, _, _, _ = ops.layernorm_fwd_f32(cls_in, ln1w, ln1b, eps, want_bf16=False)
+    qf, qb, _ = ops.linear_f32(hn0f, wq, bq, want_bf16=True)
     # dropout sites (model_cross.py:97,101,25,27): probabilities, proj output, after GELU, FFN output
-    oc, pr = ops.cls_xattn_fwd(q, kv, B, N, H, scale, dropout=(p, seeds[0]))
-    cls_in = xi.reshape(B, N * d)[:, :d]                   # un-normed CLS rows (the residual, :112)
-    y = _linear(oc, wp_s, bias=bp, residual=cls_in, out_dtype=torch.float32, dropout=_dp(p, seeds[1]))
-    h2, mu2, rs2 = ops.layernorm_fwd(y, ln2w, ln2b, eps)
-    z = torch.empty(B, w1_s.shape[0], dtype=torch.bfloat16, device=xi.device)
-    a = _linear(h2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z, dropout=_dp(p, seeds[2]))
-    y2 = _linear(a, w2_s, bias=b2, residual=y, out_dtype=torch.float32, dropout=_dp(p, seeds[3]))
-    return y2, (xi, xj, mu, rs, hn, kv, q, oc, pr, y, mu2, rs2, h2, z, a)
+    oc, pr, ocf = ops.cls_xattn_fwd(qf, kv, B, N, H, scale, dropout=(p, seeds[0]), want_f32=True)
+    y, _, _ = ops.linear_f32(ocf, wp, bp, residual=cls_in, dropout=_dp(p, seeds[1]))
+    h2f, h2, mu2, rs2 = ops.layernorm_fwd_f32(y, ln2w, ln2b, eps)
+    af, a, z = ops.linear_f32(h2f, w1, b1, act=ops.ACT_GELU, want_z=True, want_bf16=True, dropout=_dp(p, seeds[2]))
+    y2, _, _ = ops.linear_f32(af, w2, b2, residual=y, dropout=_dp(p, seeds[3]))
+    return y2, (xi, xj, mu, rs, hn, kv, qb, oc, pr, y, mu2, rs2, h2, z, a)
 
 
 def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, pd=0.0, seeds=(0, 0, 0, 0)):
@@ -447,7 +453,8 @@ class CrossFusionFn(Function):
         bkv = torch.cat((bk, bv)).detach()
         xi2, xj2 = _f32c(xi).reshape(B * N, d), _f32c(xj).reshape(B * N, d)
         seeds = drop_seeds(4) if p > 0.0 else (0, 0, 0, 0)
-        y2, saved = cross_forward(xi2, xj2, B, N, H, eps, ln1w, ln1b, sh[0], bq, sh[1], bkv, sh[2], bp, ln2w, ln2b, sh[3], b1, sh[4], b2, p, seeds)
+        y2, saved = cross_forward(xi2, xj2, B, N, H, eps, ln1w, ln1b, wq.detach(), bq, sh[1], bkv, wp.detach(), bp, ln2w, ln2b, w1.detach(), b1,
+                                  w2.detach(), b2, p, seeds)
         ctx.drop = (p, seeds)
         ctx.meta = (B, N, H, d, concat)
         ctx.save_for_backward(ln1w, ln2w, *sh, *saved)
@@ -550,12 +557,12 @@ class HeadFn(Function):
     def forward(ctx, x, lnw, lnb, w0, b0, w3, b3, eps, p=0.0):
         B, N, d = x.shape
         x2 = _f32c(x).reshape(B, N * d)[:, :d]              # CLS rows, ld = N*d
-        h, mu, rs = ops.layernorm_fwd(x2, lnw, lnb, eps)
+        # one row per sample: fp32 operands throughout (see cross_forward); bf16 copies only feed the backward chain
+        hf, h, mu, rs = ops.layernorm_fwd_f32(x2, lnw, lnb, eps)
         w0_s = SHADOWS.get(w0)
-        z = torch.empty(B, w0.shape[0], dtype=torch.bfloat16, device=x.device)
         seeds = drop_seeds(2) if p > 0.0 else (0, 0)
-        a = _linear(h, w0_s, bias=b0, act=ops.ACT_GELU, aux=z, dropout=_dp(p, seeds[0]))   # mlp_head[m][2]
-        logits = ops.small_linear_fwd(a, w3.detach(), b3.detach())
+        af, a, z = ops.linear_f32(hf, w0.detach(), b0.detach(), act=ops.ACT_GELU, want_z=True, want_bf16=True, dropout=_dp(p, seeds[0]))   # mlp_head[m][0..2]
+        logits, _, _ = ops.linear_f32(af, w3.detach(), b3.detach())
         if p > 0.0:                                                                     # mlp_head[m][4]: dropout on the logits
             ops.dropout(logits, p, seeds[1], out=logits)
         ctx.drop = (p, seeds)

@@ -23,6 +23,15 @@ def _stream() -> int:
 # launch with HIP events recorded on the launch stream and appends
 # (kernel family, algorithmic work, "flop" | "byte", start_event, end_event).
 PROFILE = None
+GEMM_TILE = 0            # mirror of xvit_set_option("gemm_tile") for the family names below
+
+
+def set_option(name: str, value: int):
+    """xvit_set_option (include/xvit.h): process-wide tuning knobs, e.g. ("gemm_tile", 1) forces the 128x128 kernel."""
+    global GEMM_TILE
+    _lib.check(_lib.load().xvit_set_option(name.encode(), int(value)), "xvit_set_option")
+    if name == "gemm_tile":
+        GEMM_TILE = int(value)
 PROFILE_SHAPES = False   # append the GEMM shape/epilogue to the family name (bench.py --detail)
 
 
@@ -118,8 +127,9 @@ def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NON
             a.workspace, a.workspace_bytes = _ptr(ws), need
     # one family per kernel symbol: gemm_big_kernel<..> (M, N >= 256) vs gemm_kernel<..>; "+splitk" brackets also
     # contain the splitk_epilogue_kernel launch that follows
-    big = a.M >= 256 and a.N >= 256 and ((a.M + 255) // 256) * ((a.N + 255) // 256) * a.batch * max(split_k, 1) > 128   # = use_big_tile() in gemm.hip
-    tag = ("gemm_big_" if big else "gemm_small_") + ("nt", "nn", "tn")[layout] + ("+splitk" if split_k > 1 else "")
+    big = GEMM_TILE != 1 and a.M >= 256 and a.N >= 256 and ((a.M + 255) // 256) * ((a.N + 255) // 256) * a.batch * max(split_k, 1) > 128   # = use_big_tile() in gemm.hip
+    kind = "big" if big else "small"
+    tag = f"gemm_{kind}_" + ("nt", "nn", "tn")[layout] + ("+splitk" if split_k > 1 else "")
     if PROFILE is not None and PROFILE_SHAPES:
         epi = ("+b" if bias is not None else "") + ("+gelu" if act == ACT_GELU else "+dgelu" if act == ACT_DGELU else "") + ("+res" if residual is not None else "")
         tag += f"[{a.M}x{a.N}x{a.K}{epi}{'' if a.c_dtype == BF16 else ',f32'}{',s%d' % split_k if split_k > 1 else ''}]"
@@ -138,8 +148,40 @@ def layernorm_fwd(x, gamma, beta, eps, *, x_alt=None, seq_len=0, out=None):
         assert x_alt.shape == x.shape and x_alt.stride() == x.stride()
     _run("layernorm_fwd", rows * d * 6.0, "byte",
          lambda: _lib.load().xvit_layernorm_fwd(_ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(gamma), _ptr(beta), eps,
-                                                _ptr(y), _rows2d(y), _ptr(mean), _ptr(rstd), rows, d, _stream()), "xvit_layernorm_fwd")
+                                                _ptr(y), _rows2d(y), None, 0, _ptr(mean), _ptr(rstd), rows, d, _stream()), "xvit_layernorm_fwd")
     return y, mean, rstd
+
+
+def layernorm_fwd_f32(x, gamma, beta, eps, want_bf16=True):
+    """x fp32 [rows, d] (row stride free) -> (y fp32, y bf16 | None, mean, rstd): the single-token CLS path keeps fp32 operands."""
+    rows, d = x.shape
+    yf = torch.empty(rows, d, dtype=torch.float32, device=x.device)
+    yb = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().xvit_layernorm_fwd(_ptr(x), None, _rows2d(x), 0, _ptr(gamma), _ptr(beta), eps, _ptr(yb), d, _ptr(yf), d,
+                                              _ptr(mean), _ptr(rstd), rows, d, _stream()), "xvit_layernorm_fwd")
+    return yf, yb, mean, rstd
+
+
+def linear_f32(x, W, bias=None, *, act=ACT_NONE, residual=None, want_z=False, want_bf16=False, dropout=None):
+    """fp32 Linear of the single-token CLS path (xvit_linear_f32): x fp32 [M, K] (row stride free), W fp32 [N, K] (the master
+    weight itself) -> (y fp32 [M, N], y bf16 | None, z bf16 | None); z = the GELU pre-activation (act = ACT_GELU)."""
+    M, K = x.shape
+    N = W.shape[0]
+    assert x.dtype == torch.float32 and W.dtype == torch.float32 and W.shape[1] == K
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    yb = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    zb = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if want_z else None
+    lib = _lib.load()
+    need = lib.xvit_linear_f32_workspace_bytes(M, N, K)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=x.device) if need else None
+    dp, seed = (float(dropout[0]), int(dropout[1])) if dropout is not None and dropout[0] > 0.0 else (0.0, 0)
+    _run("linear_f32", 2.0 * M * N * K, "flop",
+         lambda: lib.xvit_linear_f32(_ptr(x), _rows2d(x), _ptr(W), _rows2d(W), _ptr(bias), _ptr(y), N, M, N, K, act, _ptr(zb), N,
+                                     _ptr(residual), _rows2d(residual) if residual is not None else 0, _ptr(yb), N, dp, seed, _ptr(ws), need, _stream()),
+         "xvit_linear_f32")
+    return y, yb, zb
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, x_alt=None, seq_len=0, dres=None, want_bf16=False, dxsum=None, dressum=None):
@@ -185,17 +227,20 @@ def attn_bwd(qkv, o, d_o, lse, B, N, H, scale):
     return dqkv
 
 
-def cls_xattn_fwd(q, kv, B, N, H, scale, dropout=(0.0, 0)):
-    """q bf16 [B, d]; kv bf16 [B*N, 2d] (k | v) -> (o bf16 [B, d], p fp32 [B, H, N])."""
+def cls_xattn_fwd(q, kv, B, N, H, scale, dropout=(0.0, 0), want_f32=False):
+    """q bf16 or fp32 [B, d]; kv bf16 [B*N, 2d] (k | v) -> (o bf16 [B, d], p fp32 [B, H, N]) (+ o fp32 with want_f32)."""
     d = q.shape[1]
     o = torch.empty(B, d, dtype=torch.bfloat16, device=q.device)
+    of = torch.empty(B, d, dtype=torch.float32, device=q.device) if want_f32 else None
     p = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
     ld = _rows2d(kv)
     kp = kv.data_ptr()
+    qb, qf = (q, None) if q.dtype == torch.bfloat16 else (None, q)
     _run("cls_xattn_fwd", B * N * 2.0 * d * 2, "byte",
-         lambda: _lib.load().xvit_cls_xattn_fwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(o), d, _ptr(p), B, H, N, d // H, scale,
+         lambda: _lib.load().xvit_cls_xattn_fwd(_ptr(qb), _rows2d(qb) if qb is not None else 0, _ptr(qf), _rows2d(qf) if qf is not None else 0,
+                                                kp, kp + 2 * d, N * ld, ld, _ptr(o), d, _ptr(of), d, _ptr(p), B, H, N, d // H, scale,
                                                 float(dropout[0]), int(dropout[1]), _stream()), "xvit_cls_xattn_fwd")
-    return o, p
+    return (o, p, of) if want_f32 else (o, p)
 
 
 def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale, dropout=(0.0, 0)):

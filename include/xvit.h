@@ -35,6 +35,10 @@ typedef void* xvit_stream_t; /* hipStream_t */
 
 int xvit_version(void);
 const char* xvit_last_error_string(void);
+/* Process-wide tuning knobs (diagnostics / A-B measurements; results never depend on them):
+ *   "gemm_tile"      0 = automatic tile choice, 1 = always the 128x128 kernel
+ *   "gemm_epilogue"  0 = automatic, 1 = always the 8-byte-per-lane epilogue (bf16 outputs normally use 16 bytes per lane) */
+int xvit_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.  Replaces every nn.Linear on the path and its autograd backward:
@@ -87,6 +91,16 @@ int xvit_gemm(const xvit_gemm_args* args, xvit_stream_t stream);
 /* scratch needed by xvit_gemm for these args (0 when none); no launch, no allocation */
 int64_t xvit_gemm_workspace_bytes(const xvit_gemm_args* args);
 
+/* fp32 Linear for the single-token CLS path (model_cross.py:91 wq, :100 proj, :112-113 the FFN on the one fused token,
+ * :177-181 the heads): y[M,N] = x[M,K] W[N,K]^T (+bias) (GELU) (dropout) (+residual), ALL fp32 (W is the master weight
+ * itself), on the f32-input MFMA; K-chunks are summed in a fixed order through the caller's workspace (deterministic).
+ * M = batch rows; K % 16 == 0.  Optional bf16 copies for the backward chain: z_bf16 = pre-activation (act = GELU),
+ * y_bf16 = the stored y.  Epilogue order as xvit_gemm.  workspace: xvit_linear_f32_workspace_bytes(M, N, K) bytes. */
+int64_t xvit_linear_f32_workspace_bytes(int M, int N, int K);
+int xvit_linear_f32(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias, float* y, int64_t ldy, int M, int N, int K,
+                    int act, void* z_bf16, int64_t ldz, const float* residual, int64_t ldr, void* y_bf16, int64_t ldyb, float dropout_p,
+                    uint64_t dropout_seed, void* workspace, int64_t workspace_bytes, xvit_stream_t stream);
+
 /* Tiny fp32 linear for shapes the MFMA tile cannot address (the num_classes=2 head,
  * model_cross.py:181).  y[M,N] = x[M,K] W[N,K]^T + b.  x is bf16, W/b/y fp32.  */
 int xvit_small_linear_fwd(const void* x_bf16, int64_t ldx, const float* W, const float* b, float* y, int M, int N, int K, xvit_stream_t stream);
@@ -100,9 +114,12 @@ int xvit_small_linear_bwd(const float* dy, const void* x_bf16, int64_t ldx, cons
  * x is the fp32 residual stream [rows, d] (row stride ldx).  If x_alt != NULL, rows with
  * (row % seq_len) == 0 are read from x_alt at the same offset: the "cls of i + patches of j"
  * concatenation of model_cross.py:140 without materialising it.
+ * Outputs: y_bf16 (the GEMM operand) and / or y_f32 (the fp32 copy the single-token CLS path feeds to xvit_linear_f32);
+ * either may be NULL, not both.
  * ---------------------------------------------------------------------------------------- */
 int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_len, const float* gamma, const float* beta,
-                       float eps, void* y_bf16, int64_t ldy, float* mean, float* rstd, int rows, int d, xvit_stream_t stream);
+                       float eps, void* y_bf16, int64_t ldy, float* y_f32, int64_t ldyf, float* mean, float* rstd, int rows, int d,
+                       xvit_stream_t stream);
 /* dx = (dres ? dres : 0) + LN'(dy); also emits a bf16 copy of dx (the next GEMMs' operand) when
  * dx_bf16 != NULL; dgamma/dbeta are ADDED (fp32 atomics).  Optional dxsum[d] += column sums of dx and
  * dressum[d] += column sums of dres: the bias gradients of the Linears on either side of the norm
@@ -128,11 +145,12 @@ int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t stride_b,
 /* ------------------------------------------------------------------------------------------
  * CLS-query cross-attention (model_cross.py:91-99): one query row per (b, h) against N keys.
  * q [B, d] bf16 (row stride ldq); k/v as above; o [B, d] bf16; p [B,H,N] fp32 probabilities
- * (saved for backward).  HBM-bound GEMV-style kernel.
+ * (saved for backward).  HBM-bound GEMV-style kernel.  q_f32 [B, d] (optional, row stride ldqf) replaces q as the query and
+ * o_f32 (optional) receives an fp32 copy of o: the single-token CLS path keeps its operands in fp32 (xvit_linear_f32).
  * ---------------------------------------------------------------------------------------- */
-int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t stride_b, int64_t stride_n, void* o,
-                       int64_t ldo, float* p, int B, int H, int N, int dh, float scale, float dropout_p, uint64_t dropout_seed,
-                       xvit_stream_t stream);
+int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const float* q_f32, int64_t ldqf, const void* k, const void* v, int64_t stride_b,
+                       int64_t stride_n, void* o, int64_t ldo, float* o_f32, int64_t ldof, float* p, int B, int H, int N, int dh, float scale,
+                       float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
 /* dropout_p / dropout_seed: attn_drop on the probabilities (model_cross.py:97); p[] holds the pre-dropout values */
 int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t stride_b, int64_t stride_n, const float* p,
                        const void* d_o, int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, int B, int H, int N, int dh,

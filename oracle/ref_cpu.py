@@ -189,9 +189,11 @@ def tensor_sha256(t: torch.Tensor) -> str:
 # --------------------------------------------------------------------------------------
 # By default every function below is the exact fp32/fp64 restatement (the form pinned against the
 # reference).  Inside `with emulate_bf16():` operands are additionally rounded to bf16 at exactly
-# the points where the HIP path stores or feeds bf16: both operands of every GEMM, the q/k/v
-# projections' outputs, and the (un-normalised) softmax probabilities fed to the P.V product.
+# the points where the HIP path stores or feeds bf16: both operands of every GEMM over ALL tokens, the
+# q/k/v projections' outputs, and the (un-normalised) softmax probabilities fed to the P.V product.
 # Accumulation stays fp32, the residual stream stays fp32 — the arithmetic class of the kernels.
+# The single-token CLS path (wq, proj and the FFN of the cross fusion, the heads: `exact=True` below)
+# runs fp32 operands on the HIP side as well (xvit_linear_f32) and is therefore not rounded here.
 # GPU-vs-emulation isolates kernel bugs from the (expected) cost of bf16 operands.
 
 _QUANT = None
@@ -240,10 +242,13 @@ def gelu(x):
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
-def linear(x, w, b=None, store=False, w_exact=False):
-    """y = x W^T + b.  Emulation mode rounds x and W (unless w_exact: the fp32 class head) and,
+def linear(x, w, b=None, store=False, exact=False):
+    """y = x W^T + b.  Emulation mode rounds x and W (unless exact: the fp32 single-token path) and,
     when `store`, the result (outputs the HIP path keeps in bf16)."""
-    y = _q(x) @ (w if w_exact else _q(w)).transpose(-1, -2)
+    if exact:
+        y = x @ w.transpose(-1, -2)
+        return y if b is None else y + b
+    y = _q(x) @ _q(w).transpose(-1, -2)
     y = y if b is None else y + b
     return _q(y) if store else y
 
@@ -274,10 +279,10 @@ def softmax_attention(q, k, v, scale):
 # --------------------------------------------------------------------------------------
 
 
-def feed_forward(sd, p, x):
+def feed_forward(sd, p, x, exact=False):
     """model_cross.py:19-31 (dropout p=0)."""
-    h = gelu(linear(x, sd[p + ".net.0.weight"], sd[p + ".net.0.bias"]))
-    return linear(h, sd[p + ".net.3.weight"], sd[p + ".net.3.bias"])
+    h = gelu(linear(x, sd[p + ".net.0.weight"], sd[p + ".net.0.bias"], exact=exact))
+    return linear(h, sd[p + ".net.3.weight"], sd[p + ".net.3.bias"], exact=exact)
 
 
 def self_attention(sd, p, x, H):
@@ -299,17 +304,17 @@ def self_block(sd, p, x, H):
 def cls_cross_attention(sd, p, x, H):
     """model_cross.py:88-102: the query is row 0 only; keys/values are all N rows."""
     d = x.shape[-1]
-    q = _split_heads(linear(x[:, 0:1], sd[p + ".wq.weight"], sd[p + ".wq.bias"], store=True), H)
+    q = _split_heads(linear(x[:, 0:1], sd[p + ".wq.weight"], sd[p + ".wq.bias"], exact=True), H)
     k = _split_heads(linear(x, sd[p + ".wk.weight"], sd[p + ".wk.bias"], store=True), H)
     v = _split_heads(linear(x, sd[p + ".wv.weight"], sd[p + ".wv.bias"], store=True), H)
     o, _ = softmax_attention(q, k, v, (d // H) ** -0.5)
-    return linear(_merge_heads(o), sd[p + ".proj.weight"], sd[p + ".proj.bias"])
+    return linear(_merge_heads(o), sd[p + ".proj.weight"], sd[p + ".proj.bias"], exact=True)
 
 
 def cross_block(sd, p, x, H):
     """model_cross.py:111-114: LN over all N rows, residual is the un-normed row 0."""
     y = cls_cross_attention(sd, p + ".attn.fn", layer_norm(x, sd[p + ".attn.norm.weight"], sd[p + ".attn.norm.bias"]), H) + x[:, 0:1]
-    y = feed_forward(sd, p + ".ffn.fn", layer_norm(y, sd[p + ".ffn.norm.weight"], sd[p + ".ffn.norm.bias"])) + y
+    y = feed_forward(sd, p + ".ffn.fn", layer_norm(y, sd[p + ".ffn.norm.weight"], sd[p + ".ffn.norm.bias"]), exact=True) + y
     return y
 
 
@@ -364,8 +369,8 @@ def model_cross_forward(sd, img, labels, cfg, capture: dict | None = None):
     per_mod = []
     for m, x in enumerate(xs):
         c = layer_norm(x, sd[f"norm.{m}.weight"], sd[f"norm.{m}.bias"])[:, 0]
-        h = gelu(linear(c, sd[f"mlp_head.{m}.0.weight"], sd[f"mlp_head.{m}.0.bias"]))
-        per_mod.append(linear(h, sd[f"mlp_head.{m}.3.weight"], sd[f"mlp_head.{m}.3.bias"], w_exact=True))
+        h = gelu(linear(c, sd[f"mlp_head.{m}.0.weight"], sd[f"mlp_head.{m}.0.bias"], exact=True))
+        per_mod.append(linear(h, sd[f"mlp_head.{m}.3.weight"], sd[f"mlp_head.{m}.3.bias"], exact=True))
     logits = torch.stack(per_mod).mean(dim=0)
     return logits, cross_entropy(logits, labels, cfg.label_smoothing)
 
@@ -441,8 +446,8 @@ def model_vit_forward(sd, img, labels, cfg, capture: dict | None = None):
         if capture is not None:
             capture[f"layer{l}"] = x
     c = layer_norm(x[:, 0], sd["mlp_head.0.weight"], sd["mlp_head.0.bias"])
-    h = gelu(linear(c, sd["mlp_head.1.weight"], sd["mlp_head.1.bias"]))
-    logits = linear(h, sd["mlp_head.4.weight"], sd["mlp_head.4.bias"], w_exact=True)
+    h = gelu(linear(c, sd["mlp_head.1.weight"], sd["mlp_head.1.bias"], exact=True))
+    logits = linear(h, sd["mlp_head.4.weight"], sd["mlp_head.4.bias"], exact=True)
     return logits, cross_entropy(logits, labels)
 
 

@@ -14,6 +14,18 @@ def _ops():
     return ops
 
 
+@pytest.fixture(autouse=True, params=[(0, 0), (1, 0), (0, 1)], ids=["auto", "tile128", "narrow-epilogue"])
+def gemm_variant(request):
+    """Every case runs under the automatic choices, with the 128x128 kernel forced, and with the 8-byte-per-lane epilogue
+    forced (bf16 outputs of the 256x256 kernel normally take the 16-byte-per-lane epilogue) — xvit_set_option."""
+    tile, epi = request.param
+    _ops().set_option("gemm_tile", tile)
+    _ops().set_option("gemm_epilogue", epi)
+    yield request.param
+    _ops().set_option("gemm_tile", 0)
+    _ops().set_option("gemm_epilogue", 0)
+
+
 def _gelu(x):
     return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
 

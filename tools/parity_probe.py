@@ -92,27 +92,28 @@ def main():
         sh = (XF.SHADOWS.get(c.wq.weight), XF.SHADOWS.get(c.wk.weight, c.wv.weight), XF.SHADOWS.get(c.proj.weight), XF.SHADOWS.get(f.fn.net[0].weight), XF.SHADOWS.get(f.fn.net[3].weight))
         bkv = torch.cat((c.wk.bias, c.wv.bias)).detach()
         xi, xj = xs[0].reshape(B * N, d).contiguous(), xs[1].reshape(B * N, d).contiguous()
-        y2, sv = XF.cross_forward(xi, xj, B, N, H, a.norm.eps, a.norm.weight, a.norm.bias, sh[0], c.wq.bias, sh[1], bkv, sh[2], c.proj.bias,
-                                  f.norm.weight, f.norm.bias, sh[3], f.fn.net[0].bias, sh[4], f.fn.net[3].bias)
+        y2, sv = XF.cross_forward(xi, xj, B, N, H, a.norm.eps, a.norm.weight, a.norm.bias, c.wq.weight.detach(), c.wq.bias, sh[1], bkv, c.proj.weight.detach(), c.proj.bias,
+                                  f.norm.weight, f.norm.bias, f.fn.net[0].weight.detach(), f.fn.net[0].bias, f.fn.net[3].weight.detach(), f.fn.net[3].bias)
         (xi_, xj_, mu, rs, hn, kv, qv, oc, pr, y, mu2, rs2, h2, z, a_) = sv
         print(f"cross fusion ({P})")
         cat = torch.cat((cpu(xs[0])[:, 0:1], cpu(xs[1])[:, 1:]), dim=1)
         line("LN(concat) -> hn (bf16)", hn.reshape(B, N, d), q(R.layer_norm(cat, sd[P + ".attn.norm.weight"], sd[P + ".attn.norm.bias"])))
         wkv = torch.cat((sd[P + ".attn.fn.wk.weight"], sd[P + ".attn.fn.wv.weight"]))
         line("kv GEMM (bf16)", kv, q(cpu(hn) @ q(wkv).T + cpu(bkv)))
-        hn0 = cpu(hn).reshape(B, N, d)[:, 0]
-        line("q = wq(cls) (bf16)", qv, q(hn0 @ q(sd[P + ".attn.fn.wq.weight"]).T + sd[P + ".attn.fn.wq.bias"]))
+        hn0 = R.layer_norm(cat, sd[P + ".attn.norm.weight"], sd[P + ".attn.norm.bias"])[:, 0]          # fp32 single-token path from here on
+        line("q = wq(cls) (bf16 copy)", qv, q(hn0 @ sd[P + ".attn.fn.wq.weight"].T + sd[P + ".attn.fn.wq.bias"]))
         kk, vv = (R._split_heads(t.reshape(B, N, d), H) for t in cpu(kv).split(d, dim=-1))
-        qq = R._split_heads(cpu(qv).reshape(B, 1, d), H)
+        qq = R._split_heads((hn0 @ sd[P + ".attn.fn.wq.weight"].T + sd[P + ".attn.fn.wq.bias"]).reshape(B, 1, d), H)
         o_ref, _ = R.softmax_attention(qq, kk, vv, (d // H) ** -0.5)
         line("cls attention oc (bf16)", oc, q(R._merge_heads(o_ref).reshape(B, d)))
-        y_ref = cpu(oc) @ q(sd[P + ".attn.fn.proj.weight"]).T + sd[P + ".attn.fn.proj.bias"] + cpu(xs[0])[:, 0]
+        y_ref = R._merge_heads(o_ref).reshape(B, d) @ sd[P + ".attn.fn.proj.weight"].T + sd[P + ".attn.fn.proj.bias"] + cpu(xs[0])[:, 0]
         line("proj + res -> y (f32)", y, y_ref)
-        line("LN2 -> h2 (bf16)", h2, q(R.layer_norm(cpu(y), sd[P + ".ffn.norm.weight"], sd[P + ".ffn.norm.bias"])))
-        pre = cpu(h2) @ q(sd[P + ".ffn.fn.net.0.weight"]).T + sd[P + ".ffn.fn.net.0.bias"]
-        line("FFN1 z (bf16)", z, q(pre))
-        line("FFN1 GELU a (bf16)", a_, q(R.gelu(pre)))
-        line("FFN2 + res -> y2 (f32)", y2, cpu(a_) @ q(sd[P + ".ffn.fn.net.3.weight"]).T + sd[P + ".ffn.fn.net.3.bias"] + cpu(y))
+        h2_ref = R.layer_norm(cpu(y), sd[P + ".ffn.norm.weight"], sd[P + ".ffn.norm.bias"])
+        line("LN2 -> h2 (bf16 copy)", h2, q(h2_ref))
+        pre = h2_ref @ sd[P + ".ffn.fn.net.0.weight"].T + sd[P + ".ffn.fn.net.0.bias"]
+        line("FFN1 z (bf16 copy)", z, q(pre))
+        line("FFN1 GELU a (bf16 copy)", a_, q(R.gelu(pre)))
+        line("FFN2 + res -> y2 (f32)", y2, R.gelu(pre) @ sd[P + ".ffn.fn.net.3.weight"].T + sd[P + ".ffn.fn.net.3.bias"] + cpu(y))
 
         # end to end, against the emulating and the exact oracle
         cap, cap32 = {}, {}
