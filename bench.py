@@ -326,6 +326,8 @@ def main():
     log(f"timed region: {ms:.2f} ms/step")
     tokens_per_s = world * B * M * P * args.steps / dt
     loss_val = float(loss.detach())
+    del loss          # frees the last step's autograd graph (a live graph pins its AccumulateGrad nodes to the streams they were created
+                      # on, which a later HIP-graph capture of the step cannot synchronise with: see xvit/graph.py)
 
     out = {
         "metric": "3D patch-tokens/sec fwd+bwd, 2-modality 128^3 p16 ViT", "value": round(tokens_per_s, 1), "unit": "patch-tokens/s",

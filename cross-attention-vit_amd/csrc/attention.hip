@@ -172,16 +172,25 @@ __device__ __forceinline__ void store_lane_rows(const f32x16 (&acc)[2], float mu
     }
 }
 
+// Probability dropout (reference model.py:169: attention_probs = attn_dropout(softmax(scores))): element (b, h, query, key) is
+// kept iff hash32(seed, ((b H + h) N + query) N + key) >= p 2^24 — the mask xvit_dropout applies to a contiguous [B, H, N, N]
+// tensor with the same seed — and scaled by 1/(1-p).  The row sums (softmax normaliser) use the probabilities BEFORE the
+// mask; the backward kernels regenerate the mask (nothing is stored) and, with O = P_drop V, delta = rowsum(dO O) is unchanged.
+struct DropArgs { uint32_t thr; float inv; uint64_t seed; };
+__device__ __forceinline__ bool drop_keep(const DropArgs& d, uint64_t bh_base, int query, int key, int N) {
+  return (hash32(d.seed, bh_base + (uint64_t)query * (uint64_t)N + (uint64_t)key) & 0xFFFFFFu) >= d.thr;
+}
+
 // ------------------------------------------------------------------------------------------
 // forward.  Each wave owns QB blocks of 32 queries (QB = 2: 64 queries per wave, 256 per workgroup).  The
 // per-wave critical path of one tile (QK^T chain -> row max -> exp -> P.V chain) is latency-bound, so two
 // independent query blocks per wave double the instruction-level parallelism, and every K / V fragment
 // read from LDS feeds 2*QB MFMAs instead of 2.
 // ------------------------------------------------------------------------------------------
-template <int QB>
+template <int QB, bool DROP>
 __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                           int64_t sb, int64_t sn, bf16* __restrict__ o, int64_t osb, int64_t osn,
-                                                          float* __restrict__ lse, int H, int N, float scale) {
+                                                          float* __restrict__ lse, int H, int N, float scale, const DropArgs drop) {
 #ifdef XVIT_DEBUG_ATTN_TIMES
   const uint64_t wc_entry = wall_clock64();
 #endif
@@ -328,6 +337,15 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
         }
       }
       l_run[qb] += psum2.x + psum2.y;
+      if constexpr (DROP) {   // mask P after the row sum, before P.V
+        const uint64_t bh_base = ((uint64_t)b * H + head) * (uint64_t)N * (uint64_t)N;
+        const int query = q0 + qb * 32 + (lane & 31);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            s[qb][kb][i] = drop_keep(drop, bh_base, query, t * TILE_ROWS + kb * 32 + acc_row(i, h), N) ? s[qb][kb][i] * drop.inv : 0.f;
+      }
     }
 #ifdef XVIT_DEBUG_ATTN_TIMES
     if (t == 3) { asm volatile("s_nop 0" ::"v"(s[0][0][0]), "v"(s[0][1][15])); tk[3] = __builtin_readcyclecounter(); }
@@ -401,10 +419,11 @@ __global__ void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __rest
 // backward, dQ: one wave = 32 queries, streams K and V tiles
 // ------------------------------------------------------------------------------------------
 // (133 VGPRs: three blocks per CU; squeezing it to 128 for a fourth spills and measured 6 % slower)
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                              int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
                                                              const float* __restrict__ nlse_ws, const float* __restrict__ delta,
-                                                             bf16* __restrict__ dq, int H, int N, float scale) {
+                                                             bf16* __restrict__ dq, int H, int N, float scale, const DropArgs drop) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
@@ -473,7 +492,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 #pragma unroll
       for (int i = 0; i < 16; ++i) {   // (hand-packed v_pk_fma / v_pk_mul here measured 4 % slower at N = 4097: left to the compiler)
         const float pv = __builtin_amdgcn_exp2f(fmaf(s[i], c, nlse));
-        s[i] = pv * (dp[i] - dlt);  // dS^T
+        float dpe = dp[i];
+        if constexpr (DROP)   // dP = mask / (1-p) * (dO V^T)
+          dpe = drop_keep(drop, ((uint64_t)b * H + head) * (uint64_t)N * (uint64_t)N, qrow, t * TILE_ROWS + kb * 32 + acc_row(i, lane >> 5), N) ? dpe * drop.inv : 0.f;
+        s[i] = pv * (dpe - dlt);  // dS^T
       }
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
@@ -492,10 +514,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 constexpr int DKV_STAGE = 2 * IMG_BYTES + 512;  // Q image | dO image | nlse[64] | delta[64]  (all four arrive by LDS-DMA)
 
 // (198 VGPRs: two blocks per CU; bounding it to 168 for a third spills and measured 7 % slower)
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                               int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
                                                               const float* __restrict__ nlse_ws, const float* __restrict__ delta,
-                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int H, int N, float scale) {
+                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int H, int N, float scale, const DropArgs drop) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
@@ -590,8 +613,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float pv = __builtin_amdgcn_exp2f(fmaf(s[g * 4 + e], c, nl[e]));
-          pr[g * 4 + e] = pv;
-          s[g * 4 + e] = pv * (dp[g * 4 + e] - dl[e]);  // dS
+          if constexpr (DROP) {   // dV uses P_drop = mask/(1-p) P; dP = mask/(1-p) (dO V^T)
+            const bool keep = drop_keep(drop, (uint64_t)stat0 * (uint64_t)N, t * TILE_ROWS + qb * 32 + 8 * g + 4 * h + e, k0 + (lane & 31), N);
+            pr[g * 4 + e] = keep ? pv * drop.inv : 0.f;
+            s[g * 4 + e] = pv * ((keep ? dp[g * 4 + e] * drop.inv : 0.f) - dl[e]);  // dS
+          } else {
+            pr[g * 4 + e] = pv;
+            s[g * 4 + e] = pv * (dp[g * 4 + e] - dl[e]);  // dS
+          }
         }
       }
 #pragma unroll
@@ -634,27 +663,38 @@ static int attn_check(const char* who, int B, int H, int N, int dh, int64_t sb, 
   return XVIT_OK;
 }
 
+static DropArgs drop_args(float p, uint64_t seed) { return DropArgs{(uint32_t)(p * 16777216.0f), 1.0f / (1.0f - p), seed}; }
+
 extern "C" int xvit_attn_fwd(const void* q, const void* k, const void* v, int64_t sb, int64_t sn, void* o, int64_t osb, int64_t osn, float* lse,
-                             int B, int H, int N, int dh, float scale, xvit_stream_t stream) {
+                             int B, int H, int N, int dh, float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream) {
   XVIT_REQUIRE(q && k && v && o && lse, "xvit_attn_fwd: null pointer");
+  XVIT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "xvit_attn_fwd: dropout_p must be in [0, 1)");
   if (int e = attn_check("xvit_attn_fwd", B, H, N, dh, sb, sn, osb, osn)) return e;
   // QB = 1 (32 queries per wave).  QB = 2 was measured: identical throughput at N = 512..4097 (the loop is bound by
   // softmax VALU issue, 12.4 VALU per MFMA at d_h = 64 — not by LDS reads or per-wave ILP) and worse at small batch.
   const dim3 grid((N + 127) / 128, H, B), block(256);
-  hipLaunchKernelGGL((attn_fwd_kernel<1>), grid, block, FWD_NST * 2 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
-                     (bf16*)o, osb, osn, lse, H, N, scale);
+  const DropArgs da = drop_args(dropout_p, dropout_seed);
+  if (dropout_p > 0.f)
+    hipLaunchKernelGGL((attn_fwd_kernel<1, true>), grid, block, FWD_NST * 2 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+                       (bf16*)o, osb, osn, lse, H, N, scale, da);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<1, false>), grid, block, FWD_NST * 2 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+                       (bf16*)o, osb, osn, lse, H, N, scale, da);
   return check_launch("xvit_attn_fwd");
 }
 
 extern "C" int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t sb, int64_t sn, const void* o, const void* d_o, int64_t osb,
                              int64_t osn, const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int N, int dh, float scale,
-                             xvit_stream_t stream) {
+                             float dropout_p, uint64_t dropout_seed, xvit_stream_t stream) {
   XVIT_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "xvit_attn_bwd: null pointer");
+  XVIT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "xvit_attn_bwd: dropout_p must be in [0, 1)");
   if (int e = attn_check("xvit_attn_bwd", B, H, N, dh, sb, sn, osb, osn)) return e;
   hipStream_t s = (hipStream_t)stream;
   static const bool lds_opt_in = [] {   // rings deeper than 3 stages need more than the default 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * DKV_STAGE);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * DKV_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * DKV_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * 2 * IMG_BYTES);
     return true;
   }();
   (void)lds_opt_in;
@@ -662,9 +702,17 @@ extern "C" int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_
   float* nlse = delta + total;   // workspace = [2][B,H,N]: delta | -lse*log2e
   hipLaunchKernelGGL(attn_delta_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, osb, osn, lse, delta, nlse, H, N, total);
   const dim3 grid((N + 127) / 128, H, B), block(256);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, BWD_NST * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
-                     osn, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb, osn,
-                     nlse, delta, (bf16*)dq, H, N, scale);
+  const DropArgs da = drop_args(dropout_p, dropout_seed);
+  if (dropout_p > 0.f) {
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, block, BWD_NST * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
+                       osn, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, da);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb, osn,
+                       nlse, delta, (bf16*)dq, H, N, scale, da);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, BWD_NST * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
+                       osn, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, da);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb, osn,
+                       nlse, delta, (bf16*)dq, H, N, scale, da);
+  }
   return check_launch("xvit_attn_bwd");
 }

@@ -15,14 +15,6 @@ def _p(module, drop):
     return float(drop.p) if module.training else 0.0
 
 
-def _no_prob_dropout(module, drop):
-    """model.py:169 drops attention PROBABILITIES; the fused attention kernel never materialises them and has
-    no mask hook yet, so training with attention_dropout_rate > 0 is refused rather than silently changed."""
-    if module.training and drop.p > 0.0:
-        raise NotImplementedError("xvit: attention_dropout_rate > 0 in training mode is not supported by the fused "
-                                  "attention kernel (dropout_rate on the MLP is); use 0 or .eval()")
-
-
 class Mlp(nn.Module):
     """model.py:107-122."""
 
@@ -53,11 +45,11 @@ class MultiHeadAttention(nn.Module):
         self.proj_dropout = nn.Dropout(t["attention_dropout_rate"])
 
     def forward(self, x):
-        _no_prob_dropout(self, self.attn_dropout)
         w = torch.cat((self.query.weight, self.key.weight, self.value.weight), dim=0)
         b = torch.cat((self.query.bias, self.key.bias, self.value.bias), dim=0)
         qkv = XF.LinearFn.apply(x, w, b, False)
-        ctxl = XF.AttentionCoreFn.apply(qkv, self.num_attention_heads, 1.0 / float(self.attention_head_size) ** 0.5)
+        # model.py:169: dropout on the attention probabilities, inside the fused kernel (counter-hash mask, regenerated in backward)
+        ctxl = XF.AttentionCoreFn.apply(qkv, self.num_attention_heads, 1.0 / float(self.attention_head_size) ** 0.5, _p(self, self.attn_dropout))
         return XF.LinearFn.apply(ctxl, self.out.weight, self.out.bias, True, _p(self, self.proj_dropout))
 
 
@@ -74,12 +66,11 @@ class Block(nn.Module):
 
     def forward(self, x):
         a, f = self.multi_head, self.ffn
-        _no_prob_dropout(self, a.attn_dropout)
         return XF.EncoderBlockFn.apply(
             x, self.attention_norm.weight, self.attention_norm.bias, a.query.weight, a.query.bias, a.key.weight, a.key.bias,
             a.value.weight, a.value.bias, a.out.weight, a.out.bias, self.ffn_norm.weight, self.ffn_norm.bias,
             f.fc1.weight, f.fc1.bias, f.fc2.weight, f.fc2.bias, a.num_attention_heads, self.attention_norm.eps,
-            _p(self, a.proj_dropout), _p(self, f.dropout))
+            _p(self, a.proj_dropout), _p(self, f.dropout), _p(self, a.attn_dropout))
 
 
 class Encoder(nn.Module):

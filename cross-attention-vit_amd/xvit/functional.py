@@ -118,6 +118,7 @@ class FlatWeights:
                 self.view16.append(self.flat16[o:o + p.numel()].view(p.shape))
                 self.index[id(p)] = i
         self.ptrs = [p.data_ptr() for p in self.params]
+        self.by_ptr = {q: i for i, q in enumerate(self.ptrs)}
         self.stamp = None
 
     def intact(self):
@@ -134,7 +135,11 @@ class FlatWeights:
         """bf16 view for one member, or for members that are neighbours with nothing between them."""
         idx = [self.index.get(id(p)) for p in params]
         if any(i is None or self.params[i] is not p for i, p in zip(idx, params)):
-            return None
+            # not the registered Parameter objects: accept leaf ALIASES of them (same storage and shape — xvit.graph.GraphedStep
+            # runs the model on detached aliases so that its captured backward owns fresh AccumulateGrad nodes)
+            idx = [self.by_ptr.get(p.data_ptr()) for p in params]
+            if any(i is None or self.params[i].shape != p.shape or p.dtype != torch.float32 for i, p in zip(idx, params)):
+                return None
         if len(idx) == 1:
             return self.view16[idx[0]]
         if any(b != a + 1 for a, b in zip(idx, idx[1:])) or any(self.params[i].numel() % 8 for i in idx[:-1]):
@@ -274,13 +279,13 @@ def _f32c(t):
 # ------------------------------------------------------------------------------------------
 
 
-def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln2w, ln2b, w1_s, b1, w2_s, b2, p_out=0.0, p_ffn=0.0, seeds=(0, 0, 0)):
+def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln2w, ln2b, w1_s, b1, w2_s, b2, p_out=0.0, p_ffn=0.0, seeds=(0, 0, 0), p_attn=0.0, seed_attn=0):
     """x fp32 [B*N, d] -> (x2 fp32 [B*N, d], saved activations).  Dropout sites (reference
     model_cross.py:47,25,27 / model.py:177,114,116): after the out-projection (p_out), after GELU and
     after the second FFN Linear (p_ffn) — all fused into the producing GEMM's epilogue."""
     h1, mu1, rs1 = ops.layernorm_fwd(x, ln1w, ln1b, eps)
     qkv = _linear(h1, wqkv_s, bias=bqkv)
-    o, lse = ops.attn_fwd(qkv, B, N, H, scale)
+    o, lse = ops.attn_fwd(qkv, B, N, H, scale, dropout=(p_attn, seed_attn))       # model.py:169: dropout on the probabilities
     x1 = _linear(o, wo_s, bias=bo, residual=x, out_dtype=torch.float32, dropout=_dp(p_out, seeds[0]))
     h2, mu2, rs2 = ops.layernorm_fwd(x1, ln2w, ln2b, eps)
     z = torch.empty(x.shape[0], w1_s.shape[0], dtype=torch.bfloat16, device=x.device)
@@ -289,7 +294,7 @@ def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln
     return x2, (x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a)
 
 
-def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w, w1_s, w2_s, p_out=0.0, p_ffn=0.0, seeds=(0, 0, 0)):
+def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w, w1_s, w2_s, p_out=0.0, p_ffn=0.0, seeds=(0, 0, 0), p_attn=0.0, seed_attn=0):
     """dy fp32 [B*N, d] -> (dx, grads dict).  Bias gradients cost no extra pass: b2 and bo fall out of the
     LN2 backward (column sums of its dres and dx), b1 out of the GELU' dgrad epilogue."""
     x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a = saved
@@ -314,7 +319,7 @@ def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w
     # attention
     do = _dgrad(dx1b, wo_s)
     g["wo"] = _wgrad(dx1b, o)
-    dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale)
+    dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale, dropout=(p_attn, seed_attn))
     dh1 = _dgrad(dqkv, wqkv_s)
     g["wqkv"] = _wgrad(dqkv, h1)
     if has_bqkv:
@@ -352,15 +357,16 @@ class EncoderBlockFn(Function):
     """model.Block: separate biased query/key/value, eps 1e-6, scores / sqrt(dh)."""
 
     @staticmethod
-    def forward(ctx, x, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps, p_out=0.0, p_ffn=0.0):
+    def forward(ctx, x, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps, p_out=0.0, p_ffn=0.0, p_attn=0.0):
         B, N, d = x.shape
         scale = 1.0 / float(d // H) ** 0.5
         sh = (SHADOWS.get(wq, wk, wv), SHADOWS.get(wo), SHADOWS.get(w1), SHADOWS.get(w2))
         bqkv = torch.cat((bq, bk, bv)).detach()
         seeds = drop_seeds(3) if (p_out > 0.0 or p_ffn > 0.0) else (0, 0, 0)
+        seed_attn = drop_seeds(1)[0] if p_attn > 0.0 else 0
         x2, saved = block_forward(_f32c(x).reshape(B * N, d), B, N, H, eps, scale, ln1w, ln1b, sh[0], bqkv, sh[1], bo, ln2w, ln2b, sh[2], b1, sh[3], b2,
-                                  p_out, p_ffn, seeds)
-        ctx.drop = (p_out, p_ffn, seeds)
+                                  p_out, p_ffn, seeds, p_attn, seed_attn)
+        ctx.drop = (p_out, p_ffn, seeds, p_attn, seed_attn)
         ctx.meta = (B, N, H, scale, d, x.dtype)
         ctx.save_for_backward(ln1w, ln2w, *sh, *saved)
         return x2.reshape(B, N, d)
@@ -372,7 +378,7 @@ class EncoderBlockFn(Function):
         dx, g = block_backward(_f32c(dy).reshape(B * N, -1), saved, B, N, H, scale, ln1w, wqkv_s, True, wo_s, ln2w, w1_s, w2_s, *ctx.drop)
         wq, wk, wv = g["wqkv"].split(d, dim=0)
         bq, bk, bv = g["bqkv"].split(d)
-        return (dx.reshape(B, N, -1).to(xdt), g["ln1w"], g["ln1b"], wq, bq, wk, bk, wv, bv, g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None, None)
+        return (dx.reshape(B, N, -1).to(xdt), g["ln1w"], g["ln1b"], wq, bq, wk, bk, wv, bv, g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------
@@ -703,20 +709,21 @@ class AttentionCoreFn(Function):
     """softmax(q k^T scale) v on a fused [B, N, 3d] qkv tensor."""
 
     @staticmethod
-    def forward(ctx, qkv, H, scale):
+    def forward(ctx, qkv, H, scale, p=0.0):
         B, N, d3 = qkv.shape
         q2 = _as_bf16_2d(qkv)
-        o, lse = ops.attn_fwd(q2, B, N, H, scale)
+        seed = drop_seeds(1)[0] if p > 0.0 else 0
+        o, lse = ops.attn_fwd(q2, B, N, H, scale, dropout=(p, seed))
         ctx.save_for_backward(q2, o, lse)
-        ctx.meta = (B, N, H, scale, qkv.dtype)
+        ctx.meta = (B, N, H, scale, qkv.dtype, p, seed)
         return o.reshape(B, N, d3 // 3)
 
     @staticmethod
     def backward(ctx, do):
         q2, o, lse = ctx.saved_tensors
-        B, N, H, scale, dt = ctx.meta
-        dqkv = ops.attn_bwd(q2, o, _as_bf16_2d(do), lse, B, N, H, scale)
-        return dqkv.reshape(B, N, -1).to(dt), None, None
+        B, N, H, scale, dt, p, seed = ctx.meta
+        dqkv = ops.attn_bwd(q2, o, _as_bf16_2d(do), lse, B, N, H, scale, dropout=(p, seed))
+        return dqkv.reshape(B, N, -1).to(dt), None, None, None
 
 
 class ClsAttentionCoreFn(Function):

@@ -11,8 +11,16 @@ graph's private pool.
     optimizer.step()                                         # outside the graph
 
 Restrictions: static shapes; dropout must be inactive (masks are seeded on the host per call, a replay would repeat
-them).  The per-modality self-attention branches fork from and join back into the capture stream, so the graph
-keeps them as parallel paths (XVIT_GRAPH_STREAMS=0 captures everything on one stream instead).
+them).  The per-modality self-attention branches and the fusions fork from and join back into the capture stream, so the
+graph keeps them as parallel paths (XVIT_GRAPH_STREAMS=branches forks the branches only, =0 captures on one stream).
+
+The captured step runs the model on detached leaf ALIASES of its parameters (torch.func.functional_call; same storage, so
+optimizer updates are seen) and takes the gradients with torch.autograd.grad, assigning them to the real p.grad.  Reason:
+backward delivers a leaf's gradient through its AccumulateGrad node, which is bound to the stream it was created on and
+stays alive as long as ANY autograd graph that used the parameter does.  If an earlier eager iteration's graph is still
+referenced (a kept `loss` is enough), those nodes sit on the default stream, the captured backward would have to hand
+gradients to a stream outside the capture, and hipStreamEndCapture crashes (torch only warns "AccumulateGrad node's
+stream does not match", once per process).  Fresh aliases get fresh nodes, created inside the capture.
 """
 from __future__ import annotations
 
@@ -31,7 +39,11 @@ class GraphedStep:
             if isinstance(m, torch.nn.Dropout) and m.p > 0 and model.training:
                 raise RuntimeError("GraphedStep: dropout is active; its host-side seeds cannot be captured (use p = 0 or eval)")
         self.model = model
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        if hasattr(model, "_sync_flat_weights") and next(model.parameters()).is_cuda and os.environ.get("XVIT_FLAT_WEIGHTS", "1") != "0":
+            model._sync_flat_weights()             # parameters move into the flat buffer at the first forward: alias them afterwards
+        self._named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in self._named]
+        self._alias = {n: p.detach().requires_grad_() for n, p in self._named}
         self.img = img.clone()
         self.labels = labels.clone()
         self._prev_streams = os.environ.get("XVIT_STREAMS")
@@ -65,9 +77,11 @@ class GraphedStep:
             for p in self.params:
                 p.grad = None
         XF.SHADOWS.force = True                # the captured step always re-casts the weights (they change every step)
-        logits, loss = self.model(self.img, self.labels)
-        loss.backward()
-        return logits, loss
+        logits, loss = torch.func.functional_call(self.model, self._alias, (self.img, self.labels))
+        grads = torch.autograd.grad(loss, [self._alias[n] for n, _ in self._named], allow_unused=True)   # see the module docstring
+        for p, g in zip(self.params, grads):
+            p.grad = g
+        return logits.detach(), loss.detach()
 
     def __call__(self, img=None, labels=None):
         if img is not None:

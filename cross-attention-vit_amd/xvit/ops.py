@@ -198,8 +198,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, x_alt=None, seq_le
     return dx, dxb
 
 
-def attn_fwd(qkv, B, N, H, scale):
-    """qkv bf16 [B*N, 3d] (q | k | v along columns) -> (o bf16 [B*N, d], lse fp32 [B, H, N])."""
+def attn_fwd(qkv, B, N, H, scale, dropout=(0.0, 0)):
+    """qkv bf16 [B*N, 3d] (q | k | v along columns) -> (o bf16 [B*N, d], lse fp32 [B, H, N]).  dropout = (p, seed): dropout
+    on the attention probabilities (model.py:169); the mask is that of ops.dropout on a [B, H, N, N] tensor with that seed."""
     d = qkv.shape[1] // 3
     dh = d // H
     o = torch.empty(B * N, d, dtype=torch.bfloat16, device=qkv.device)
@@ -207,12 +208,13 @@ def attn_fwd(qkv, B, N, H, scale):
     ld = _rows2d(qkv)
     p = qkv.data_ptr()
     _run("attn_fwd", 4.0 * B * H * N * N * dh, "flop",
-         lambda: _lib.load().xvit_attn_fwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), N * d, d, _ptr(lse), B, H, N, dh, scale, _stream()),
+         lambda: _lib.load().xvit_attn_fwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), N * d, d, _ptr(lse), B, H, N, dh, scale,
+                                           float(dropout[0]), int(dropout[1]), _stream()),
          "xvit_attn_fwd")
     return o, lse
 
 
-def attn_bwd(qkv, o, d_o, lse, B, N, H, scale):
+def attn_bwd(qkv, o, d_o, lse, B, N, H, scale, dropout=(0.0, 0)):
     """-> dqkv bf16 [B*N, 3d]."""
     d = qkv.shape[1] // 3
     dh = d // H
@@ -223,7 +225,7 @@ def attn_bwd(qkv, o, d_o, lse, B, N, H, scale):
     p, g = qkv.data_ptr(), dqkv.data_ptr()
     _run("attn_bwd", 10.0 * B * H * N * N * dh, "flop",
          lambda: _lib.load().xvit_attn_bwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), _ptr(d_o), N * d, d, _ptr(lse), _ptr(delta),
-                                           g, g + 2 * d, g + 4 * d, B, H, N, dh, scale, _stream()), "xvit_attn_bwd")
+                                           g, g + 2 * d, g + 4 * d, B, H, N, dh, scale, float(dropout[0]), int(dropout[1]), _stream()), "xvit_attn_bwd")
     return dqkv
 
 

@@ -134,13 +134,17 @@ int xvit_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, const 
  * without materialising the [B,H,N,N] scores.  Element (b, n, h, :) of q/k/v lives at
  * ptr + b*stride_b + n*stride_n + h*dh (q, k, v normally point into one [B,N,3d] tensor).
  * dh must be 64.  lse[B,H,N] = log-sum-exp of the scaled scores (saved for backward).
+ * dropout_p > 0 (model.py:169 attn_dropout on the probabilities): element (b, h, q, k) is kept iff
+ * hash(seed, ((b*H + h)*N + q)*N + k) >= p * 2^24 (the mask xvit_dropout applies to a contiguous [B, H, N, N] tensor with that
+ * seed), scaled by 1/(1-p), applied after the softmax normalisation; the backward regenerates it from the same (p, seed).
  * ---------------------------------------------------------------------------------------- */
 int xvit_attn_fwd(const void* q, const void* k, const void* v, int64_t stride_b, int64_t stride_n, void* o, int64_t o_stride_b,
-                  int64_t o_stride_n, float* lse, int B, int H, int N, int dh, float scale, xvit_stream_t stream);
+                  int64_t o_stride_n, float* lse, int B, int H, int N, int dh, float scale, float dropout_p, uint64_t dropout_seed,
+                  xvit_stream_t stream);
 /* delta: caller-provided fp32 workspace of 2*B*H*N floats (rowsum(do*o), then -lse*log2e).  dq/dk/dv use the q/k/v strides. */
 int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t stride_b, int64_t stride_n, const void* o, const void* d_o,
                   int64_t o_stride_b, int64_t o_stride_n, const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H,
-                  int N, int dh, float scale, xvit_stream_t stream);
+                  int N, int dh, float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * CLS-query cross-attention (model_cross.py:91-99): one query row per (b, h) against N keys.

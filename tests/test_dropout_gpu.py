@@ -113,16 +113,57 @@ def test_model_cross_trains_with_reference_dropout_rates():
     assert rel(e1, ref_logits) < 2.5e-2
 
 
-def test_encoder_refuses_probability_dropout_in_training_only():
+@pytest.mark.parametrize("B,H,N", [(2, 3, 65), (1, 2, 200), (1, 12, 513)])
+def test_flash_attention_probability_dropout_exact_mask(B, H, N):
+    """model.py:169 drops attention PROBABILITIES.  The fused kernels apply a counter-hash mask keyed by (seed, b, h, q, k): the
+    very mask is extracted (xvit_dropout on ones [B, H, N, N]) and fed to the oracle; forward and all three gradients agree."""
+    from xvit import ops
+    d, p, seed, scale = H * 64, 0.3, 987654321, 0.125
+    qkv = rt(randn(B, N, 3 * d, seed=N))
+    do = rt(randn(B, N, d, seed=N + 1))
+    qd = qkv.to(dev(), torch.bfloat16).reshape(B * N, 3 * d)
+    o, lse = ops.attn_fwd(qd, B, N, H, scale, dropout=(p, seed))
+    dqkv = ops.attn_bwd(qd, o, do.to(dev(), torch.bfloat16).reshape(B * N, d), lse, B, N, H, scale, dropout=(p, seed))
+    mask = _mask((B, H, N, N), p, seed)                      # 0 or 1/(1-p)
+    assert abs(float((mask != 0).float().mean()) - (1 - p)) < 0.02
+    heads = lambda t: t.reshape(B, N, H, 64).permute(0, 2, 1, 3)   # noqa: E731
+    q, k, v = (heads(t).clone().requires_grad_() for t in qkv.split(d, dim=-1))
+    pr = torch.softmax((q @ k.transpose(-1, -2)) * scale, dim=-1)
+    o_ref = (pr * mask) @ v
+    assert_close(heads(o.reshape(B, N, d)), o_ref, "flash fwd with probability dropout")
+    assert_close(lse, torch.logsumexp((q @ k.transpose(-1, -2)) * scale, dim=-1), "lse is that of the un-dropped softmax")
+    o_ref.backward(heads(do))
+    dq, dk, dv = (heads(t) for t in dqkv.float().cpu().reshape(B, N, 3 * d).split(d, dim=-1))
+    assert rel(dv, v.grad) < 4e-3 and rel(dk, k.grad) < 6e-3 and rel(dq, q.grad) < 6e-3, (rel(dv, v.grad), rel(dk, k.grad), rel(dq, q.grad))
+    # p = 0 launches the plain kernels: bit-identical to a call without the argument
+    o0, _ = ops.attn_fwd(qd, B, N, H, scale)
+    o1, _ = ops.attn_fwd(qd, B, N, H, scale, dropout=(0.0, seed))
+    assert torch.equal(o0, o1)
+
+
+def test_encoder_trains_with_attention_probability_dropout():
+    """The model.py twin with attention_dropout_rate > 0 (model.py:169, :177) in training mode: runs, is reproducible under the
+    same seed state, differs between calls, and eval mode equals the p = 0 encoder."""
     import xvit
+    import xvit.functional as XF
     from types import SimpleNamespace
-    cfg = SimpleNamespace(hidden_size=256, transformer=dict(num_heads=4, mlp_dim=512, dropout_rate=0.1, attention_dropout_rate=0.1, num_layers=1))
-    enc = xvit.Encoder(cfg).to(dev())
+    cfg = SimpleNamespace(hidden_size=256, transformer=dict(num_heads=4, mlp_dim=512, dropout_rate=0.1, attention_dropout_rate=0.1, num_layers=2))
+    torch.manual_seed(0)
+    enc = xvit.Encoder(cfg).to(dev()).train()
     x = randn(2, 17, 256, seed=1).to(dev())
-    with pytest.raises(NotImplementedError):
-        enc(x)
+    XF._DROP_CALLS = 500
+    y1 = enc(x)
+    y1.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+    y2 = enc(x)
+    assert not torch.equal(y1, y2)
+    XF._DROP_CALLS = 500
+    assert torch.equal(enc(x), y1)
+    cfg0 = SimpleNamespace(hidden_size=256, transformer=dict(num_heads=4, mlp_dim=512, dropout_rate=0.0, attention_dropout_rate=0.0, num_layers=2))
+    enc0 = xvit.Encoder(cfg0).to(dev()).train()
+    enc0.load_state_dict(enc.state_dict())
     enc.eval()
-    assert torch.isfinite(enc(x)).all()
-    cfg.transformer["attention_dropout_rate"] = 0.0
-    enc2 = xvit.Encoder(cfg).to(dev()).train()
-    enc2(x).sum().backward()                                         # MLP dropout alone is supported
+    assert torch.equal(enc(x), enc0(x))
+    # stand-alone MultiHeadAttention takes the same path
+    mha = xvit.MultiHeadAttention(cfg).to(dev()).train()
+    mha(x).sum().backward()

@@ -43,3 +43,26 @@ def test_graphed_step_matches_eager_and_follows_new_inputs():
     assert float(loss) != e1[1]
     ref = eager(img1, lab1)
     assert rel(logits, ref[0]) < 1e-6 and abs(float(loss) - ref[1]) < 1e-6
+
+
+def test_graphed_step_survives_a_stale_autograd_graph():
+    """A kept `loss` pins the parameters' AccumulateGrad nodes to the default stream; a captured loss.backward() then crashed
+    inside hipStreamEndCapture (bench.py hit it).  GraphedStep takes gradients with autograd.grad, which never runs those
+    nodes: capture works with the stale graph alive and gives the eager gradients."""
+    import xvit
+    from xvit.graph import GraphedStep
+    cfg = R.make_config("tiny")
+    model = xvit.ModelCross(cfg).to(dev())
+    model.load_state_dict(R.make_state_dict(cfg, seed=0))
+    model.train()
+    img, lab = R.make_inputs(cfg, 4, seed=0)
+    img, lab = img.to(dev()), lab.to(dev())
+    _, loss = model(img, lab)
+    loss.backward()                      # `loss` (and with it the graph) stays alive on purpose
+    ref = {k: p.grad.clone() for k, p in model.named_parameters()}
+    step = GraphedStep(model, img, lab)
+    _, loss_g = step()
+    torch.cuda.synchronize()
+    assert float(loss_g) == float(loss.detach())
+    for k, p in model.named_parameters():
+        assert rel(p.grad, ref[k]) < 1e-5 or float(ref[k].abs().max()) < 1e-6, k

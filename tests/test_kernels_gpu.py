@@ -78,6 +78,42 @@ def test_attention_fwd_bwd(B, H, N):
         assert rel(dq, qr.grad) < 6e-3, rel(dq, qr.grad)
 
 
+def _attn_bwd_emulated(q, k, v, o_dev, do, lse, scale):
+    """The backward kernels' arithmetic on the CPU: P recomputed from the forward's lse, delta from the DEVICE o (bf16), and
+    P / dS rounded to bf16 where they feed the second MFMA of their product (attention.hip: dV^T += dO^T P, dK^T += Q^T dS,
+    dQ += dS K).  fp32 everywhere else."""
+    s = (q @ k.transpose(-1, -2)) * scale
+    p = torch.exp(s - lse[..., None])
+    dp = do @ v.transpose(-1, -2)
+    delta = (do * o_dev).sum(-1, keepdim=True)
+    ds = p * (dp - delta)
+    dv = rt(p).transpose(-1, -2) @ do
+    dk = rt(ds).transpose(-1, -2) @ q * scale
+    dq = rt(ds) @ k * scale
+    return dq, dk, dv
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 12, 513), (1, 2, 3376), (1, 2, 4097), (2, 3, 130)])
+def test_attention_bwd_vs_bf16_emulating_oracle(B, H, N):
+    """Gate with the kernels' own rounding points emulated (bf16 P and dS into the second product): 3e-3 = 1e-3 + one bf16
+    output rounding, also at the long-sequence tile counts of configs[2] (N = 3376: 53 key tiles) and configs[4]
+    (N = 4097: 65 key tiles, several rounds of the XCD block remap)."""
+    ops = _ops()
+    d = H * 64
+    scale = 64 ** -0.5
+    qkv = rt(randn(B, N, 3 * d, seed=N + 7))
+    do = rt(randn(B, N, d, seed=N + 8))
+    qd = qkv.to(dev(), torch.bfloat16).reshape(B * N, 3 * d)
+    o, lse = ops.attn_fwd(qd, B, N, H, scale)
+    dqkv = ops.attn_bwd(qd, o, do.to(dev(), torch.bfloat16).reshape(B * N, d), lse, B, N, H, scale)
+    heads = lambda t: t.reshape(B, N, H, 64).permute(0, 2, 1, 3)   # noqa: E731
+    q, k, v = (heads(t) for t in qkv.split(d, dim=-1))
+    rq, rk, rv = _attn_bwd_emulated(q, k, v, heads(o.float().cpu().reshape(B, N, d)), heads(do), lse.cpu(), scale)
+    dq, dk, dv = (heads(t) for t in dqkv.float().cpu().reshape(B, N, 3 * d).split(d, dim=-1))
+    for name, got, ref in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        assert rel(got, ref) < 3e-3, (name, rel(got, ref))
+
+
 def test_attention_online_softmax_rescale_branch():
     """Force the running max to jump at a late key tile (guide rule 26): one key aligned with one
     query and scaled up, placed in the last tile."""

@@ -4,14 +4,17 @@ by oracle/make_golden.py from the reference's own code) and against the CPU orac
 Two gates:
 
  (1) TIGHT — HIP path vs the CPU oracle in `emulate_bf16()` mode, i.e. the same fp32-accumulate
-     arithmetic with operands rounded to bf16 at the same points (both GEMM operands, stored
-     q/k/v, P into P.V).  What remains is accumulation order and the rounding of stored
-     activations: block outputs and logits must agree to 3e-3 (observed ~1e-3).
+     arithmetic with operands rounded to bf16 at the same points (both operands of every all-token
+     GEMM, stored q/k/v, P into P.V; the single-token CLS path is fp32 on both sides).  What remains
+     is accumulation order and the rounding of stored activations: block outputs agree to 3e-3
+     (measured 0.9-1.5e-3 at configs[1]), CLS rows to 5.5e-3 (3.8-4.6e-3), logits to 9e-3 (6.7e-3).
  (2) BUDGET — HIP path vs the REFERENCE's own fp32 outputs (goldens; un-rounded fp32 weights).
-     bf16 operands alone move the result: the CPU emulation of this arithmetic measures
-     6-8e-3 on CLS rows and 0.9-1.7e-2 on the (tiny, cancellation-heavy) logits against the same
-     goldens, the reference's own pure-bf16 run 3e-3..9e-3 on blocks.  Gates: full block outputs
-     6e-3, CLS rows 1e-2, logits 2.5e-2, loss 5e-3 absolute, gradients 2e-2 / norms 3 %.
+     bf16 operands alone move the result: the CPU emulation of this arithmetic measures 2.9-3.4e-3
+     on block outputs, 5.2-6.3e-3 on CLS rows and 1.2e-2 on the (tiny, cancellation-heavy) logits against
+     the same goldens at configs[1] — the kernels sit at exactly those distances.  Gates: full block
+     outputs 6e-3, CLS rows 8e-3, logits 1.8e-2, loss 5e-3 absolute, gradients 2e-2 / norms 3 %.
+     (tools/parity_probe.py prints every stage in isolation: each kernel is at 1e-5 .. 3e-5 of the
+     oracle on its own inputs except flash attention, 1.3-1.8e-3 = the bf16 rounding of P.)
 """
 import os
 from types import SimpleNamespace
@@ -21,7 +24,7 @@ import pytest
 import torch
 
 import ref_cpu as R
-from _util import dev, rel
+from _util import dev, randn, rel
 
 pytestmark = pytest.mark.gpu
 
@@ -138,12 +141,14 @@ def test_model_cross_vs_reference_golden(golden_dir, name, batch):
     g = np.load(os.path.join(golden_dir, f"model_cross_{name}.npz"))
     cfg, sd, img, labels, model, caps, logits, loss = _run_model(name, batch)
     assert str(g["img_sha256"]) == R.tensor_sha256(img)  # same inputs the reference saw
-    assert rel(logits, _t(g["logits"])) < 2.5e-2, rel(logits, _t(g["logits"]))
+    # logits: 2-class sums with heavy cancellation (|logit| ~ 0.01 .. 0.3 from a head whose terms are O(1)); measured 1.4e-2 at
+    # configs[1], of which the bf16-emulating oracle shows 1.2e-2 itself (the CLS rows it feeds on differ by 5e-3 from fp32)
+    assert rel(logits, _t(g["logits"])) < 1.8e-2, rel(logits, _t(g["logits"]))
     assert abs(float(loss.detach()) - float(g["loss"])) < 5e-3
     for b in range(cfg.num_multi_blocks):
         for m in range(cfg.num_modalities):
             t = caps[b][m]
-            assert rel(t[:, 0], _t(g[f"msb{b}/mod{m}/cls"])) < 1e-2
+            assert rel(t[:, 0], _t(g[f"msb{b}/mod{m}/cls"])) < 8e-3
             assert rel(t.norm(dim=-1), _t(g[f"msb{b}/mod{m}/rownorm"])) < 2e-3
             if f"msb{b}/mod{m}/full" in g:
                 assert rel(t, _t(g[f"msb{b}/mod{m}/full"])) < BLOCK_TOL
@@ -176,11 +181,12 @@ def test_model_cross_vs_bf16_emulating_oracle(name, batch):
     for b in range(cfg.num_multi_blocks):
         for m in range(cfg.num_modalities):
             assert rel(caps[b][m], cap[f"msb{b}"][m]) < 3e-3, (b, m, rel(caps[b][m], cap[f"msb{b}"][m]))
-            assert rel(caps[b][m][:, 0], cap[f"msb{b}"][m][:, 0]) < 8e-3  # one token, many bf16 stages: rounding flips
-    # the 2-class logits are small sums with heavy cancellation fed by ONE token that crossed ~20 bf16
-    # rounding stages: a different (equally valid) accumulation order flips roundings, so two bf16
-    # evaluations sit as far from each other as each sits from fp32 (gate 2)
-    assert rel(logits, ref_logits) < 2.5e-2, rel(logits, ref_logits)
+            # the CLS row is the sum of bf16-operand attention / FFN updates with no large residual to dilute their rounding
+            # (it starts at |cls_token + pos| ~ 0.03): measured 3.8e-3 .. 4.6e-3 at configs[1]
+            assert rel(caps[b][m][:, 0], cap[f"msb{b}"][m][:, 0]) < 5.5e-3
+    # everything behind the fused CLS token runs fp32 operands on both sides (xvit_linear_f32 / oracle `exact`): what is left is
+    # the CLS rows' own deviation amplified by the cancellation in the 2-class head; measured 6.7e-3 at configs[1]
+    assert rel(logits, ref_logits) < 9e-3, rel(logits, ref_logits)
     assert abs(float(loss) - float(ref_loss)) < 2e-3
 
 
@@ -294,6 +300,33 @@ def test_large_configs_vs_bf16_emulating_oracle(name, batch):
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
         if not k.endswith("wk.bias"):
             assert float(p.grad.abs().max()) > 0, k
+
+
+@pytest.mark.parametrize("N", [3376, 4097])
+def test_self_attention_block_long_sequence_forward_and_gradients(N):
+    """One SelfAttentionBlock at the sequence lengths of configs[2] (N = 3376) and configs[4] (N = 4097), d = 768, 12 heads:
+    output, input gradient and EVERY parameter gradient against the oracle's autograd (not just finiteness)."""
+    import xvit
+    cfg = R.make_config("base")
+    sd = R.make_state_dict(cfg, seed=0)
+    pfx = "transformer.0.blocks.0.0"
+    blk = xvit.SelfAttentionBlock(cfg).to(dev())
+    blk.load_state_dict({k[len(pfx) + 1:]: v for k, v in sd.items() if k.startswith(pfx + ".")})
+    blk.train()
+    x = randn(1, N, cfg.hidden_dim, seed=N)
+    w = randn(1, N, cfg.hidden_dim, seed=N + 1)                    # d loss / d y
+    xr = x.to(dev()).requires_grad_()
+    y = blk(xr)
+    (y * w.to(dev())).sum().backward()
+    leaf = {k: v.clone().requires_grad_() for k, v in sd.items() if k.startswith(pfx + ".")}
+    xo = x.clone().requires_grad_()
+    yo = R.self_block(leaf, pfx, xo, cfg.num_heads)
+    (yo * w).sum().backward()
+    assert rel(y, yo) < BLOCK_TOL, rel(y, yo)
+    assert rel(xr.grad, xo.grad) < GRAD_TOL, rel(xr.grad, xo.grad)
+    for k, p in blk.named_parameters():
+        ref = leaf[pfx + "." + k].grad
+        assert rel(p.grad, ref) < GRAD_TOL, (k, rel(p.grad, ref))
 
 
 def test_model_vit_vs_reference_golden_and_emulation(golden_dir):
