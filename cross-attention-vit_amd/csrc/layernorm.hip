@@ -66,7 +66,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const bf16* __re
                                                                const float* __restrict__ gamma, const float* __restrict__ dres, int64_t lddres,
                                                                float* __restrict__ dx, int64_t lddx, bf16* __restrict__ dxb, int64_t lddxb,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum,
-                                                               float* __restrict__ dressum, int rows, int d) {
+                                                               float* __restrict__ dressum, float* __restrict__ part, int rows, int d) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = (float*)smem_raw;  // [LNB_WAVES][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -152,15 +152,40 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const bf16* __re
       float a = 0.f, b = 0.f;
 #pragma unroll
       for (int w = 0; w < LNB_WAVES; ++w) { a += red[(w * 2 + 0) * d + c]; b += red[(w * 2 + 1) * d + c]; }
-      if (round == 0) { unsafeAtomicAdd(dgamma + c, a); unsafeAtomicAdd(dbeta + c, b); }
+      if (part) {   // deterministic form: per-block partial sums [block][4][d], added up in block order by ln_bwd_reduce_kernel
+        part[((int64_t)blockIdx.x * 4 + round * 2 + 0) * d + c] = a;
+        part[((int64_t)blockIdx.x * 4 + round * 2 + 1) * d + c] = b;
+      } else if (round == 0) { unsafeAtomicAdd(dgamma + c, a); unsafeAtomicAdd(dbeta + c, b); }
       else { if (dxsum) unsafeAtomicAdd(dxsum + c, a); if (dressum) unsafeAtomicAdd(dressum + c, b); }
     }
+  }
+}
+
+// dgamma / dbeta / dxsum / dressum += sum over blocks of part[block][k][c], in block order (bit-reproducible)
+__global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dxsum,
+                                     float* __restrict__ dressum, int blocks, int d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  float* const dst[4] = {dgamma, dbeta, dxsum, dressum};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (!dst[k]) continue;
+    float acc = dst[k][c];
+    for (int b = 0; b < blocks; ++b) acc += part[((int64_t)b * 4 + k) * d + c];
+    dst[k][c] = acc;
   }
 }
 
 }  // namespace xvit
 
 using namespace xvit;
+
+extern "C" int64_t xvit_layernorm_bwd_workspace_bytes(int rows, int d) {
+  if (rows <= 0 || d <= 0) return 0;
+  int g = (rows + LNB_WAVES - 1) / LNB_WAVES;
+  if (g > 768) g = 768;
+  return (int64_t)g * 4 * d * (int64_t)sizeof(float);
+}
 
 static int ln_grid(int rows) {
   const int want = (rows + LN_WAVES - 1) / LN_WAVES;
@@ -187,7 +212,7 @@ extern "C" int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ld
 extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len,
                                   const float* mean, const float* rstd, const float* gamma, const float* dres, int64_t lddres, float* dx,
                                   int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, float* dxsum, float* dressum, int rows,
-                                  int d, xvit_stream_t stream) {
+                                  int d, float* workspace, int64_t workspace_bytes, xvit_stream_t stream) {
   XVIT_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "xvit_layernorm_bwd: null pointer");
   XVIT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 4096, "xvit_layernorm_bwd: need 0 < d <= 4096, d %% 4 == 0 (d=%d rows=%d)", d, rows);
   XVIT_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0) && (!dxb || lddxb % 4 == 0),
@@ -197,15 +222,21 @@ extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, 
   hipStream_t s = (hipStream_t)stream;
   int g = (rows + LNB_WAVES - 1) / LNB_WAVES;
   if (g > 768) g = 768;  // every block adds its dgamma/dbeta partials to the SAME d addresses: more blocks = atomic contention (measured slower)
+  XVIT_REQUIRE(!workspace || workspace_bytes >= (int64_t)g * 4 * d * (int64_t)sizeof(float), "xvit_layernorm_bwd: workspace too small (%lld bytes)",
+               (long long)workspace_bytes);
   const dim3 grid(g), block(LNB_WAVES * 64);
   const size_t lds = (size_t)LNB_WAVES * 2 * d * sizeof(float);
   const bf16* dyb = (const bf16*)dy;
   bf16* dxbb = (bf16*)dxb;
   if (d <= 768)
-    hipLaunchKernelGGL((ln_bwd_kernel<3>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, rows, d);
+    hipLaunchKernelGGL((ln_bwd_kernel<3>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, workspace, rows, d);
   else if (d <= 1024)
-    hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, rows, d);
+    hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, workspace, rows, d);
   else
-    hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, rows, d);
+    hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, workspace, rows, d);
+  if (workspace) {
+    // without dxsum / dressum the kernel skips round 1: those slices of the workspace are never read either
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 255) / 256), dim3(256), 0, s, workspace, dgamma, dbeta, dxsum, dressum, g, d);
+  }
   return check_launch("xvit_layernorm_bwd");
 }

@@ -101,8 +101,11 @@ __device__ __forceinline__ f32x4 ld4(const T* p) {
     return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
   }
 }
+// `part` != nullptr: deterministic form — each row chunk stores its partial sums to part[chunk][n] (plain stores) and
+// colsum_reduce_kernel adds them up in chunk order; otherwise the chunks meet in fp32 atomics on `out`.
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out, int rows, int n, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t ldx, float* __restrict__ out, float* __restrict__ part, int rows, int n,
+                                                     int rows_per_block) {
   __shared__ f32x4 red[4][64];
   const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + cq) * 4;
@@ -123,9 +126,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   __syncthreads();
   if (rl == 0 && col < n) {
     const f32x4 acc = red[0][cq] + red[1][cq] + red[2][cq] + red[3][cq];
+    if (part) {
+      *(f32x4*)(part + (int64_t)blockIdx.y * n + col) = acc;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out + col + e, acc[e]);
+      for (int e = 0; e < 4; ++e) unsafeAtomicAdd(out + col + e, acc[e]);
+    }
   }
+}
+
+// out[c] (+)= sum over chunks of part[chunk][c], in chunk order (bit-reproducible)
+__global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int chunks, int n, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float acc = accumulate ? out[c] : 0.f;
+  for (int k = 0; k < chunks; ++k) acc += part[(int64_t)k * n + c];
+  out[c] = acc;
 }
 
 template <typename T>
@@ -273,18 +289,33 @@ extern "C" int xvit_cast_f32_bf16(const float* src, void* dst, int64_t n, xvit_s
   return check_launch("xvit_cast_f32_bf16");
 }
 
-extern "C" int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, int n, int accumulate, xvit_stream_t stream) {
-  XVIT_REQUIRE(x && out && rows > 0 && n > 0, "xvit_colsum: bad arguments");
-  XVIT_REQUIRE(n % 4 == 0 && ldx % 4 == 0, "xvit_colsum: n and ldx must be multiples of 4");
-  hipStream_t s = (hipStream_t)stream;
-  if (!accumulate)   // a kernel, not hipMemsetAsync: the memset node was observed not to replay from a captured HIP graph
-    hipLaunchKernelGGL(zero_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, n);
+static int colsum_rows_per_block(int rows, int n) {
   const int gx = (n / 4 + 63) / 64;
   int rpb = 64;                                   // rows per block: >= 64, and at most ~2048 blocks in all
   while ((int64_t)gx * ((rows + rpb - 1) / rpb) > 2048) rpb *= 2;
+  return rpb;
+}
+
+extern "C" int64_t xvit_colsum_workspace_bytes(int rows, int n) {
+  if (rows <= 0 || n <= 0) return 0;
+  const int rpb = colsum_rows_per_block(rows, n);
+  return (int64_t)((rows + rpb - 1) / rpb) * n * (int64_t)sizeof(float);
+}
+
+extern "C" int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, int n, int accumulate, float* workspace,
+                           int64_t workspace_bytes, xvit_stream_t stream) {
+  XVIT_REQUIRE(x && out && rows > 0 && n > 0, "xvit_colsum: bad arguments");
+  XVIT_REQUIRE(n % 4 == 0 && ldx % 4 == 0, "xvit_colsum: n and ldx must be multiples of 4");
+  XVIT_REQUIRE(!workspace || workspace_bytes >= xvit_colsum_workspace_bytes(rows, n), "xvit_colsum: workspace too small (%lld bytes)", (long long)workspace_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate && !workspace)   // a kernel, not hipMemsetAsync: the memset node was observed not to replay from a captured HIP graph
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, n);
+  const int gx = (n / 4 + 63) / 64;
+  const int rpb = colsum_rows_per_block(rows, n);
   const dim3 grid(gx, (rows + rpb - 1) / rpb), block(256);
-  if (x_dtype == XVIT_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, ldx, out, rows, n, rpb);
-  else hipLaunchKernelGGL((colsum_kernel<bf16>), grid, block, 0, s, (const bf16*)x, ldx, out, rows, n, rpb);
+  if (x_dtype == XVIT_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, s, (const float*)x, ldx, out, workspace, rows, n, rpb);
+  else hipLaunchKernelGGL((colsum_kernel<bf16>), grid, block, 0, s, (const bf16*)x, ldx, out, workspace, rows, n, rpb);
+  if (workspace) hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, workspace, out, (int)grid.y, n, accumulate);
   return check_launch("xvit_colsum");
 }
 
@@ -304,9 +335,9 @@ extern "C" int xvit_small_linear_fwd(const void* x, int64_t ldx, const float* W,
 }
 
 extern "C" int xvit_small_linear_bwd(const float* dy, const void* x, int64_t ldx, const float* W, const void* z, int64_t ldz, void* dx, int64_t lddx,
-                                     float* dW, float* db, int M, int N, int K, xvit_stream_t stream) {
+                                     float* dW, float* db, int M, int N, int K, int deterministic, xvit_stream_t stream) {
   XVIT_REQUIRE(dy && x && W && dx && dW && db && M > 0 && N > 0 && K >= N, "xvit_small_linear_bwd: bad arguments");
-  const int rows = 8;
+  const int rows = deterministic ? M : 8;   // one row chunk: every dW / db element receives exactly one add (bit-reproducible, slower)
   hipLaunchKernelGGL(small_linear_bwd_kernel, dim3((K + 255) / 256, (M + rows - 1) / rows), dim3(256), 0, (hipStream_t)stream, dy, (const bf16*)x, ldx, W,
                      (const bf16*)z, ldz, (bf16*)dx, lddx, dW, db, M, N, K, rows);
   return check_launch("xvit_small_linear_bwd");

@@ -27,10 +27,10 @@ class GemmArgs(C.Structure):
 SIGNATURES = {
     "xvit_gemm": [C.POINTER(GemmArgs), vp],
     "xvit_small_linear_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
-    "xvit_small_linear_bwd": [vp, vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, vp],
+    "xvit_small_linear_bwd": [vp, vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
     "xvit_layernorm_fwd": [vp, vp, i64, i32, vp, vp, f32, vp, i64, vp, i64, vp, vp, i32, i32, vp],
     "xvit_linear_f32": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, f32, u64, vp, i64, vp],
-    "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp],
+    "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, i64, vp],
     "xvit_attn_fwd": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_cls_xattn_fwd": [vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
@@ -39,7 +39,7 @@ SIGNATURES = {
     "xvit_cls_row_fwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_embed_bwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_cast_f32_bf16": [vp, vp, i64, vp],
-    "xvit_colsum": [vp, i32, i64, vp, i32, i32, i32, vp],
+    "xvit_colsum": [vp, i32, i64, vp, i32, i32, i32, vp, i64, vp],
     "xvit_dropout": [vp, vp, i32, i64, f32, u64, vp],
     "xvit_cu_trace": [vp, i32, i32, vp],
     "xvit_binary_metrics_step": [vp, i64, vp, i32, i32, vp, vp],
@@ -48,7 +48,8 @@ SIGNATURES = {
     "xvit_set_option": [C.c_char_p, i32],
     "xvit_adam_step": [vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp],
 }
-EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string", "xvit_gemm_workspace_bytes", "xvit_linear_f32_workspace_bytes"])
+EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string", "xvit_gemm_workspace_bytes", "xvit_linear_f32_workspace_bytes",
+                                    "xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes"])
 
 _lib = None
 
@@ -69,6 +70,9 @@ def load() -> C.CDLL:
         lib.xvit_gemm_workspace_bytes.restype = C.c_int64
         lib.xvit_linear_f32_workspace_bytes.argtypes = [i32, i32, i32]
         lib.xvit_linear_f32_workspace_bytes.restype = C.c_int64
+        for name in ("xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes"):
+            getattr(lib, name).argtypes = [i32, i32]
+            getattr(lib, name).restype = C.c_int64
         lib.xvit_version.restype = C.c_int
         lib.xvit_last_error_string.restype = C.c_char_p
         _lib = lib

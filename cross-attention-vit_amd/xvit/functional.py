@@ -255,7 +255,10 @@ def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None, colsum=None, dropout=None):
     is accumulated by the GEMM epilogue itself on every tile path."""
     m, n, k = dy_b.shape[0], w_s.shape[1], w_s.shape[0]
     dx = torch.empty(m, n, dtype=torch.bfloat16, device=dy_b.device)
-    ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=colsum, dropout=dropout, split_k=_skinny_split(m, n, k))
+    fused = None if ops.DETERMINISTIC else colsum          # the epilogue's column sums meet in fp32 atomics
+    ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=fused, dropout=dropout, split_k=_skinny_split(m, n, k))
+    if colsum is not None and fused is None:
+        ops.colsum(dx, out=colsum, accumulate=True)        # fixed-order two-pass sum of the stored (bf16) values
     return dx
 
 

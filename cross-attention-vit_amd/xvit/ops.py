@@ -4,6 +4,7 @@ is not on the GPU is an error."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -23,6 +24,18 @@ def _stream() -> int:
 # launch with HIP events recorded on the launch stream and appends
 # (kernel family, algorithmic work, "flop" | "byte", start_event, end_event).
 PROFILE = None
+# Deterministic gradients (SURVEY.md 8(b) "Determinism"): XVIT_DETERMINISTIC=1 or set_deterministic(True).  The kernels that
+# normally meet in fp32 atomics (LayerNorm dgamma / dbeta and the bias column sums next to it, xvit_colsum, the class-head
+# wgrad) then store per-block partial sums and add them in a fixed order, and the GEMM epilogue's fused column sums are
+# replaced by a separate xvit_colsum: every .grad is bit-identical from run to run (attention backward and split-K already are).
+DETERMINISTIC = os.environ.get("XVIT_DETERMINISTIC", "0") == "1"
+
+
+def set_deterministic(on: bool = True):
+    global DETERMINISTIC
+    DETERMINISTIC = bool(on)
+
+
 GEMM_TILE = 0            # mirror of xvit_set_option("gemm_tile") for the family names below
 
 
@@ -191,10 +204,14 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, x_alt=None, seq_le
     dx = torch.empty(rows, d, dtype=torch.float32, device=x.device)
     dxb = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     nbytes = rows * d * (2.0 + 4.0 + 4.0 + (4.0 if dres is not None else 0.0) + (2.0 if want_bf16 else 0.0))
+    ws, ws_bytes = None, 0
+    if DETERMINISTIC:
+        ws_bytes = _lib.load().xvit_layernorm_bwd_workspace_bytes(rows, d)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     _run("layernorm_bwd", nbytes, "byte", lambda: _lib.load().xvit_layernorm_bwd(
         _ptr(dy), _rows2d(dy), _ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(mean), _ptr(rstd), _ptr(gamma),
         _ptr(dres), _rows2d(dres) if dres is not None else 0, _ptr(dx), d, _ptr(dxb), d,
-        _ptr(dgamma), _ptr(dbeta), _ptr(dxsum), _ptr(dressum), rows, d, _stream()), "xvit_layernorm_bwd")
+        _ptr(dgamma), _ptr(dbeta), _ptr(dxsum), _ptr(dressum), rows, d, _ptr(ws), ws_bytes, _stream()), "xvit_layernorm_bwd")
     return dx, dxb
 
 
@@ -304,8 +321,12 @@ def colsum(x, out=None, accumulate=False):
     if out is None:
         out = torch.empty(n, dtype=torch.float32, device=x.device)
         accumulate = False
+    ws, ws_bytes = None, 0
+    if DETERMINISTIC:
+        ws_bytes = _lib.load().xvit_colsum_workspace_bytes(rows, n)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
     _run("colsum", float(rows) * n * x.element_size(), "byte",
-         lambda: _lib.load().xvit_colsum(_ptr(x), _dt(x), _rows2d(x), _ptr(out), rows, n, int(accumulate), _stream()), "xvit_colsum")
+         lambda: _lib.load().xvit_colsum(_ptr(x), _dt(x), _rows2d(x), _ptr(out), rows, n, int(accumulate), _ptr(ws), ws_bytes, _stream()), "xvit_colsum")
     return out
 
 
@@ -330,7 +351,7 @@ def small_linear_bwd(dy, x, W, dW, db, z=None):
     N = W.shape[0]
     dx = torch.empty(M, K, dtype=torch.bfloat16, device=x.device)
     _lib.check(_lib.load().xvit_small_linear_bwd(_ptr(dy), _ptr(x), _rows2d(x), _ptr(W), _ptr(z), _rows2d(z) if z is not None else 0,
-                                                 _ptr(dx), K, _ptr(dW), _ptr(db), M, N, K, _stream()), "xvit_small_linear_bwd")
+                                                 _ptr(dx), K, _ptr(dW), _ptr(db), M, N, K, int(DETERMINISTIC), _stream()), "xvit_small_linear_bwd")
     return dx
 
 

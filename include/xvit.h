@@ -107,7 +107,8 @@ int xvit_small_linear_fwd(const void* x_bf16, int64_t ldx, const float* W, const
 /* dx[M,K] (bf16) = (dy W) * (z ? gelu'(z) : 1);  dW[N,K] += dy^T x;  db[N] += colsum(dy).  dy fp32.
  * z (bf16 [M,K], optional) is the pre-activation of the GELU that produced x (model_cross.py:178). */
 int xvit_small_linear_bwd(const float* dy, const void* x_bf16, int64_t ldx, const float* W, const void* z_bf16, int64_t ldz,
-                          void* dx_bf16, int64_t lddx, float* dW, float* db, int M, int N, int K, xvit_stream_t stream);
+                          void* dx_bf16, int64_t lddx, float* dW, float* db, int M, int N, int K, int deterministic, xvit_stream_t stream);
+/* deterministic != 0: one row chunk instead of 8-row chunks meeting in fp32 atomics (bit-reproducible, slower) */
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (model_cross.py:11-17 PreNorm, :174/:203 final norm; model.py:186-187,207 eps=1e-6).
@@ -127,7 +128,11 @@ int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_
 int xvit_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len,
                        const float* mean, const float* rstd, const float* gamma, const float* dres, int64_t lddres,
                        float* dx, int64_t lddx, void* dx_bf16, int64_t lddxb, float* dgamma, float* dbeta, float* dxsum,
-                       float* dressum, int rows, int d, xvit_stream_t stream);
+                       float* dressum, int rows, int d, float* workspace, int64_t workspace_bytes, xvit_stream_t stream);
+/* workspace (optional, xvit_layernorm_bwd_workspace_bytes(rows, d) bytes): the deterministic form — per-block partial sums
+ * are stored there and added to dgamma / dbeta / dxsum / dressum in block order by a second small kernel instead of by fp32
+ * atomics (bit-reproducible run to run; SURVEY.md 8(b) "Determinism"). */
+int64_t xvit_layernorm_bwd_workspace_bytes(int rows, int d);
 
 /* ------------------------------------------------------------------------------------------
  * Fused self-attention (model_cross.py:53-60; model.py:165-172): softmax(q k^T * scale) v
@@ -188,8 +193,11 @@ int xvit_embed_bwd(const float* dx, float* dpos, float* dcls, int MB, int N, int
 
 /* ---- elementwise / reductions --------------------------------------------------------- */
 int xvit_cast_f32_bf16(const float* src, void* dst_bf16, int64_t n, xvit_stream_t stream);
-/* out[n] (+)= sum_r x[r, n];  x bf16 or fp32 */
-int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, int n, int accumulate, xvit_stream_t stream);
+/* out[n] (+)= sum_r x[r, n];  x bf16 or fp32.  workspace (optional, xvit_colsum_workspace_bytes(rows, n) bytes): the row chunks'
+ * partial sums are stored there and added in chunk order (bit-reproducible) instead of meeting in fp32 atomics on out. */
+int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, int n, int accumulate, float* workspace, int64_t workspace_bytes,
+                xvit_stream_t stream);
+int64_t xvit_colsum_workspace_bytes(int rows, int n);
 /* dropout with a counter-based mask (same (seed, element index) -> same mask in fwd and bwd):
  * y = x * keep / (1-p).  In-place allowed.  dtype XVIT_BF16 | XVIT_F32. */
 int xvit_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, xvit_stream_t stream);
