@@ -187,6 +187,15 @@ __device__ __forceinline__ bool drop_keep(const DropArgs& d, uint64_t bh_base, i
 // independent query blocks per wave double the instruction-level parallelism, and every K / V fragment
 // read from LDS feeds 2*QB MFMAs instead of 2.
 // ------------------------------------------------------------------------------------------
+// -DXVIT_KNOCKOUT_HALF_MFMA (diagnostic build, WRONG results): the forward kernel issues half of its QK^T and P.V MFMAs —
+// the matrix-pipe time an MX-fp8 (v_mfma_scale_f32_32x32x64_f8f6f4, 2x the bf16 rate) version of both products would have,
+// with none of its extra quantisation work.  Timing it bounds what fp8 QK^T / AV could gain (DESIGN.md section 7, configs[4]).
+#ifdef XVIT_KNOCKOUT_HALF_MFMA
+constexpr int FWD_KS = 2, FWD_SS = 1;
+#else
+constexpr int FWD_KS = 4, FWD_SS = 2;
+#endif
+
 template <int QB, bool DROP>
 __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                           int64_t sb, int64_t sn, bf16* __restrict__ o, int64_t osb, int64_t osn,
@@ -268,14 +277,14 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
     // S^T[key][query] = K Q^T: every K fragment is read once and used by all QB query blocks
     f32x16 s[QB][2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {   // the first MFMA of each chain takes a literal-zero accumulator: no v_mov initialisation
+    for (int ks = 0; ks < FWD_KS; ++ks) {   // the first MFMA of each chain takes a literal-zero accumulator: no v_mov initialisation
       const bf16x8 kf = rd.row_frag(kimg, 0, ks);
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) s[qb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? ZERO16 : s[qb][0], 0, 0, 0);
     }
     if (two) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int ks = 0; ks < FWD_KS; ++ks) {
         const bf16x8 kf = rd.row_frag(kimg, 1, ks);
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) s[qb][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ks], ks == 0 ? ZERO16 : s[qb][1], 0, 0, 0);
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
     for (int kb = 0; kb < 2; ++kb) {
       if (kb == 1 && !two) break;
 #pragma unroll
-      for (int ss = 0; ss < 2; ++ss) {
+      for (int ss = 0; ss < FWD_SS; ++ss) {
         bf16x8 pf[QB];
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) pf[qb] = acc_frag(s[qb][kb], ss);

@@ -29,6 +29,7 @@ struct GemmParams {
   float* colsum;        // optional [N] fp32: += column sums of the stored C
   float drop_p, drop_inv; uint64_t drop_seed;   // dropout after the activation, before the residual (p == 0: off)
   int narrow_epi;                // force the 8-byte-per-lane epilogue (A/B measurements)
+  int ncg;                       // gemm_big_kernel: column tiles per super-column of the tile walk
 };
 
 // ---- the fused epilogue, shared by both tile kernels and the split-K reduce kernel -------------
@@ -782,7 +783,14 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   const int q8 = total >> 3, r8 = total & 7, xcd = lin & 7;
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (lin >> 3);
   const int zz = logical / nblk, tile = logical - zz * nblk;
-  const int tm = tile / p.ntn, tn = tile - tm * p.ntn;
+  // Within one (batch, split) the tiles are walked super-column by super-column: p.ncg column tiles wide, row tiles outermost
+  // inside it, columns fastest.  The ~32 tiles an XCD runs at one time then share a few A row-panels AND a W slice narrow
+  // enough to stay in its 4 MiB L2 across row-panels (with all N / 256 column tiles fastest, a 3072-wide Linear re-streams
+  // its whole 4.7 MB weight matrix for every 2-3 row-panels: 689 MB fetched per FFN1 launch against 104 MB of operands).
+  const int grp = min(tile / (p.ntm * p.ncg), (p.ntn - 1) / p.ncg);
+  const int rem = tile - grp * p.ntm * p.ncg;
+  const int gw = min(p.ncg, p.ntn - grp * p.ncg);
+  const int tm = rem / gw, tn = grp * p.ncg + (rem - tm * gw);
   const int m0 = tm * TBM, n0 = tn * TBN;
   const int batch = zz / p.split_k, split = zz - batch * p.split_k;
   const int k_begin = split * p.k_per_split;
@@ -864,6 +872,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // (e.g. the reference's batch 8: M = 4104 rows -> 17 x 3 big tiles for a d-wide GEMM).
 static std::atomic<int> g_gemm_tile{0};      // xvit_set_option("gemm_tile"): 0 = auto, 1 = always the 128x128 kernel
 static std::atomic<int> g_gemm_epi{0};       // xvit_set_option("gemm_epilogue"): 0 = auto, 1 = always the 8-byte-per-lane epilogue
+static std::atomic<int> g_gemm_group{0};     // xvit_set_option("gemm_group"): 0 = auto, n > 0 = column tiles per super-column of the 256x256 tile walk
 
 static bool use_big_tile(const xvit_gemm_args* a) {
   if (a->M < 256 || a->N < 256 || g_gemm_tile.load(std::memory_order_relaxed) == 1) return false;
@@ -875,6 +884,7 @@ extern "C" int xvit_set_option(const char* name, int value) {
   XVIT_REQUIRE(name != nullptr, "xvit_set_option: null name");
   const std::string n(name);
   if (n == "gemm_tile") { XVIT_REQUIRE(value == 0 || value == 1, "xvit_set_option: gemm_tile must be 0 (auto) or 1 (128x128 only)"); g_gemm_tile = value; return 0; }
+  if (n == "gemm_group") { XVIT_REQUIRE(value >= 0 && value <= 4096, "xvit_set_option: gemm_group must be in [0, 4096]"); g_gemm_group = value; return 0; }
   if (n == "gemm_epilogue") { XVIT_REQUIRE(value == 0 || value == 1, "xvit_set_option: gemm_epilogue must be 0 (auto) or 1 (narrow)"); g_gemm_epi = value; return 0; }
   set_error("xvit_set_option: unknown option '%s'", name);
   return XVIT_ERR_ARG;
@@ -934,6 +944,7 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   XVIT_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "xvit_gemm: dropout_p must be in [0, 1)");
   p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
   p.narrow_epi = g_gemm_epi.load(std::memory_order_relaxed);
+  p.ncg = 1;
   hipStream_t s = (hipStream_t)stream;
 
   static std::once_flag attr_once;   // the library is re-entrant: concurrent first calls from several host threads
@@ -951,6 +962,12 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   });
   if (big) {
     p.ntm = (a->M + TBM - 1) / TBM; p.ntn = (a->N + TBN - 1) / TBN;
+    {
+      // measured at M = 64638, K = 768 (tools/gemm_model_bench.py): forward Linears with >= 6 column tiles gain 4-14 % from
+      // super-columns of 3 (qkv 238 -> 204 us, kv 152 -> 141, FFN1 406 -> 391); dgrads / wgrads and narrow outputs do not
+      const int forced = g_gemm_group.load(std::memory_order_relaxed);
+      p.ncg = forced > 0 ? std::min(forced, p.ntn) : (a->layout == XVIT_GEMM_NT && p.ntn >= 6 ? 3 : p.ntn);
+    }
     const dim3 grid(p.ntm * p.ntn, 1, a->batch * a->split_k), block(512);
     // bf16 C with nothing but bias / activation / column sums behind it: the 16-byte-per-lane epilogue (forward Linears use
     // NONE or GELU, dgrads NONE or GELU'; wgrads store fp32; with dropout the narrow kernels run)

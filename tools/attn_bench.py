@@ -13,7 +13,7 @@ from xvit import ops  # noqa: E402
 def main():
     dev = torch.device("cuda:0")
     H = 12
-    for B, N in [(32, 513), (32, 512), (8, 513), (4, 4097)]:
+    for B, N in [(126, 513), (126, 512), (8, 513), (8, 4097)]:
         d = H * 64
         qkv = torch.randn(B * N, 3 * d, device=dev).bfloat16()
         do = torch.randn(B * N, d, device=dev).bfloat16()

@@ -74,7 +74,8 @@ def cases():
     return out
 
 
-VARIANTS = {"auto": (("gemm_tile", 0), ("gemm_epilogue", 0)), "narrow": (("gemm_tile", 0), ("gemm_epilogue", 1)), "tile128": (("gemm_tile", 1), ("gemm_epilogue", 0))}
+VARIANTS = {"auto": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", 0)), "narrow": (("gemm_tile", 0), ("gemm_epilogue", 1)), "tile128": (("gemm_tile", 1), ("gemm_epilogue", 0)),
+            **{f"g{n}": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", n)) for n in (1, 2, 3, 4, 6, 12)}}
 
 
 def main():
@@ -102,7 +103,7 @@ def main():
         ideal = max(flops / 2516e6, byt / 6.3e6)
         print(f"{label:22s} x{w}  ideal {ideal:6.0f} us | " + " | ".join(f"{v}: {best[v]:7.1f} us {flops / best[v] / 1e6:6.0f} TF {byt / best[v] / 1e3:5.0f} GB/s" for v in names), flush=True)
     print("per-step GEMM time (weighted by launches per step, ms): " + "  ".join(f"{v}: {total[v] / 1e3:.2f}" for v in names))
-    ops.set_option("gemm_tile", 0); ops.set_option("gemm_epilogue", 0)
+    ops.set_option("gemm_tile", 0); ops.set_option("gemm_epilogue", 0); ops.set_option("gemm_group", 0)
 
 
 if __name__ == "__main__":
