@@ -413,6 +413,21 @@ __device__ __forceinline__ void big_tile_mma(const XVIT_LDS char* sa, const XVIT
 // (residual row modulo, output segment gaps) are stepped incrementally instead of divided per body.
 // Every global access goes through a buffer resource with the out-of-range offset trick instead of a branch
 // (loads return 0, stores are dropped), so the bodies form straight-line code and their loads batch.
+// Cache policy of the epilogue's global traffic (the `aux` operand of the buffer instructions: 0 = default, 2 = nt, 16 = sc1).
+// Outputs and the z operand of GELU' are streamed once; written through / read non-temporally they stop evicting the A / W
+// panels the tiles of an XCD share through its 4 MiB L2.
+// Measured at configs[1] (tools/gemm_model_bench.py, same box, ms of GEMM time per step): default policy 25.0, sc1 stores 24.8,
+// nt stores + nt z loads 24.2, + nt residual loads 24.0 (FFN1 with its two bf16 outputs 411 -> 354 us, GELU' dgrad 413 -> 381,
+// out-proj 156 -> 146).
+#ifndef XVIT_EPI_STORE_AUX
+#define XVIT_EPI_STORE_AUX 2
+#endif
+#ifndef XVIT_EPI_LOAD_AUX
+#define XVIT_EPI_LOAD_AUX 2
+#endif
+#ifndef XVIT_EPI_RES_AUX
+#define XVIT_EPI_RES_AUX 2
+#endif
 typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2_t;
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
 constexpr uint32_t OOB = 0xFFFFFFF0u;
@@ -448,7 +463,7 @@ __device__ __forceinline__ void big_epi_issue_aux(const GemmParams& p, const Big
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     const bool ok = e.col_ok && lc.row < (uint32_t)p.M;
-    L.aux[b] = __builtin_amdgcn_raw_buffer_load_b64(e.raux, ok ? lc.aux : OOB, 0, 0);
+    L.aux[b] = __builtin_amdgcn_raw_buffer_load_b64(e.raux, ok ? lc.aux : OOB, 0, XVIT_EPI_LOAD_AUX);
     lc.row += 4; lc.aux += e.aux_step;
   }
 }
@@ -457,13 +472,13 @@ template <int ACT, bool DROP>
 __device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32x4 v, u32x2_t auxv) {
   const bool ok = e.col_ok && e.row < (uint32_t)p.M;
   if (e.to_slab) {   // split-K partial sums, [M][N] fp32
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rslab, ok ? e.slab : OOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rslab, ok ? e.slab : OOB, 0, XVIT_EPI_STORE_AUX);
   } else {
     v += e.bias;
     if (ACT == XVIT_ACT_GELU) {
       if (e.has_aux) {
         bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, z), e.raux, ok ? e.aux : OOB, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, z), e.raux, ok ? e.aux : OOB, 0, XVIT_EPI_STORE_AUX);
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
@@ -478,14 +493,14 @@ __device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32
 #pragma unroll
       for (int c = 0; c < 4; ++c) v[c] = (hash32(p.drop_seed, idx + c) & 0xFFFFFFu) >= thr ? v[c] * p.drop_inv : 0.f;
     }
-    if (e.has_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rres, ok ? e.res : OOB, 0, 0));
+    if (e.has_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rres, ok ? e.res : OOB, 0, XVIT_EPI_RES_AUX));
     if (p.c_f32) {
       const uint32_t off = ok ? e.c : OOB;
       if (p.accumulate) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rc, off, 0, 0));
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rc, off, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), e.rc, off, 0, XVIT_EPI_STORE_AUX);
     } else {
       bf16x4 o = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), e.rc, ok ? e.c : OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, o), e.rc, ok ? e.c : OOB, 0, XVIT_EPI_STORE_AUX);
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) e.csum[c] += ok ? v[c] : 0.f;   // the lane's 4 columns are the same in every body
@@ -567,7 +582,7 @@ __device__ __forceinline__ void wide_issue_aux(const GemmParams& p, const WideEp
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const bool ok = e.col_ok && lc.row < (uint32_t)p.M;
-    L.aux[b] = __builtin_amdgcn_raw_buffer_load_b128(e.raux, ok ? lc.aux : OOB, 0, 0);
+    L.aux[b] = __builtin_amdgcn_raw_buffer_load_b128(e.raux, ok ? lc.aux : OOB, 0, XVIT_EPI_LOAD_AUX);
     lc.row += 8; lc.aux += e.aux_step;
   }
 }
@@ -598,7 +613,7 @@ template <int ACT, bool DROP>
 __device__ __forceinline__ void wide_body(const GemmParams& p, WideEpi& e, f32x4 v0, f32x4 v1, u32x4_t auxv) {
   const bool ok = e.col_ok && e.row < (uint32_t)p.M;
   v0 += e.bias0; v1 += e.bias1;
-  if (ACT == XVIT_ACT_GELU && e.has_aux) __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v0, v1), e.raux, ok ? e.aux : OOB, 0, 0);
+  if (ACT == XVIT_ACT_GELU && e.has_aux) __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v0, v1), e.raux, ok ? e.aux : OOB, 0, XVIT_EPI_STORE_AUX);
   const bf16x8 z = __builtin_bit_cast(bf16x8, auxv);
   const uint64_t idx = e.drop_base + (uint64_t)e.row * p.N + e.col;
   // the two halves one after the other (a scheduling fence between them): eight interleaved GELU / hash evaluations
@@ -606,7 +621,7 @@ __device__ __forceinline__ void wide_body(const GemmParams& p, WideEpi& e, f32x4
   wide_half<ACT, DROP>(p, v0, bf16x4{z[0], z[1], z[2], z[3]}, idx);
   if (ACT != XVIT_ACT_NONE || DROP) __builtin_amdgcn_sched_barrier(0);
   wide_half<ACT, DROP>(p, v1, bf16x4{z[4], z[5], z[6], z[7]}, idx + 4);
-  __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v0, v1), e.rc, ok ? e.c : OOB, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v0, v1), e.rc, ok ? e.c : OOB, 0, XVIT_EPI_STORE_AUX);
 #pragma unroll
   for (int c = 0; c < 4; ++c) { e.csum0[c] += ok ? v0[c] : 0.f; e.csum1[c] += ok ? v1[c] : 0.f; }
   e.row += 8; e.c += e.c_step; e.aux += e.aux_step;

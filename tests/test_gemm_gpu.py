@@ -35,7 +35,9 @@ def _dgelu(x):
 
 
 SHAPES = [(64, 128, 64), (200, 192, 128), (1026, 768, 768), (130, 576, 192), (513, 2304, 768), (33, 3072, 768), (2, 768, 768),
-          (256, 256, 64), (1300, 1000, 320), (2052, 768, 3072)]  # the last rows run on the 256x256 big-tile kernel
+          (256, 256, 64), (1300, 1000, 320), (2052, 768, 3072),
+          (4100, 2304, 128), (2600, 3072, 64), (9000, 1536, 192), (33000, 768, 64)]  # > 128 tiles of 256x256: the big-tile kernel (the first three
+                                                                                    # with >= 6 column tiles: super-column tile walk, ragged last group)
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
@@ -73,9 +75,9 @@ def test_tn_wgrad(M, N, K, split):
     assert_close(C, 2 * (dy.T @ x), f"TN accumulate {M}x{N}x{K} split{split}")
 
 
-def test_epilogue_bias_gelu_aux():
+@pytest.mark.parametrize("M,N,K", [(513, 768, 192), (2600, 3072, 128), (4100, 2560, 64)])
+def test_epilogue_bias_gelu_aux(M, N, K):
     ops = _ops()
-    M, N, K = 513, 768, 192
     a, w, b = rt(randn(M, K, seed=1)), rt(randn(N, K, seed=2, scale=K ** -0.5)), randn(N, seed=3, scale=0.1)
     C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
     Z = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
