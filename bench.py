@@ -33,10 +33,21 @@ sys.path.insert(0, os.path.join(ROOT, "cross-attention-vit_amd"))
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-# HBM bytes per launch of the dominant kernel family, from the rocprofv3 --pmc passes committed under profiles/
-# (FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950 correction + WRITE_SIZE), averaged over the family's launches
-# of one step at the default batch.  Filled in from profiles/r01_pmc_traffic.md; None = not measured.
-TRAFFIC = {"gemm_big_nt": 8.52e8, "gemm_big_nn": 6.38e8, "gemm_big_tn+splitk": 5.95e8}   # bytes per launch at the default batch (126): profiles/r01_c_summary.md
+def load_traffic():
+    """HBM bytes per launch of each kernel family, from the newest rocprofv3 PMC summary committed under profiles/
+    (`tools/profile_session.sh` + `tools/profile_summary.py`: separate --pmc FETCH_SIZE / WRITE_SIZE passes over this very
+    command, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note).  PMC counters cannot be collected from inside the
+    timed process, so `roofline.traffic` quotes that file (and names it); None when the batch differs or no file exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, {}, None
+    try:
+        d = json.load(open(files[-1]))
+        return os.path.basename(files[-1]), d.get("traffic", {}), d.get("per_gpu_batch")
+    except Exception:
+        return None, {}, None
+
 
 MFMA_PEAK_TF = 2516.0   # bf16 dense, MI355X_MICROARCH.md: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
 HBM_PEAK_GBS = 8000.0   # HBM3E spec
@@ -405,11 +416,13 @@ def main():
                 k.update(bound="hbm", achieved=round(rate / 1e9, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(rate / 1e9 / HBM_PEAK_GBS, 4))
             kernels[name] = k
         dom = next(k for k in kernels if "+splitk" not in k)   # a family that is exactly one kernel symbol
+        t_file, t_map, t_batch = load_traffic()
         out["roofline"] = {"kernel": dom, **{k: kernels[dom][k] for k in ("bound", "achieved", "peak", "unit", "frac")},
-                           "avg_launch_us": kernels[dom]["avg_us"], "traffic": TRAFFIC.get(dom),
+                           "avg_launch_us": kernels[dom]["avg_us"], "traffic": t_map.get(dom) if t_batch == B else None,
+                           "traffic_source": f"profiles/{t_file}" if t_file and t_batch == B else None,
                            "note": "family with the largest share of step time; algorithmic FLOPs of all its launches / their summed duration "
                                    "(HIP events on the launch stream, modality streams merged while pricing); traffic = HBM bytes per launch "
-                                   "from rocprofv3 PMC passes (profiles/), FETCH_SIZE doubled per the gfx950 note"}
+                                   "from the rocprofv3 PMC passes of this command committed under profiles/ (FETCH_SIZE doubled per the gfx950 note)"}
         out["kernels"] = kernels
         # the north-star's attention target, stated separately
         if "attn_fwd" in kernels:

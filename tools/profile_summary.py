@@ -83,6 +83,23 @@ def main():
         _, wm = write[k]
         L.append(f"| `{k}` | {n} | {2 * fm:.1f} | {wm:.1f} | {2 * fm + wm:.1f} |")
     L.append("")
+    # per bench family (bench.py prices families, rocprofv3 lists kernel symbols): HBM bytes per launch, launch-weighted
+    fam_of = (("gemm_big_kernel<false, false", "gemm_big_nt"), ("gemm_big_kernel<false, true", "gemm_big_nn"), ("gemm_big_kernel<true, true", "gemm_big_tn+splitk"),
+              ("attn_fwd_kernel", "attn_fwd"), ("ln_fwd_kernel", "layernorm_fwd"), ("ln_bwd_kernel", "layernorm_bwd"), ("cast_kernel", "cast_f32_bf16"),
+              ("patchify_kernel", "patchify"))
+    fam = defaultdict(lambda: [0, 0.0])
+    for k in set(fetch) & set(write):
+        for pat, name in fam_of:
+            if pat in k:
+                n = fetch[k][0]
+                fam[name][0] += n
+                fam[name][1] += n * (2 * fetch[k][1] + write[k][1]) * 1e6
+    traffic = {name: round(v[1] / v[0]) for name, v in fam.items() if v[0]}
+    with open(os.path.join(out, f"{tag}_traffic.json"), "w") as f:
+        json.dump({"unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, launch-weighted over the family's kernels)",
+                   "per_gpu_batch": bench["config"]["per_gpu_batch"], "traffic": traffic}, f, indent=1)
+        f.write("\n")
+    L.append(f"Per bench family (`{tag}_traffic.json`, read by bench.py for `roofline.traffic`): " + ", ".join(f"{k} {v / 1e6:.0f} MB" for k, v in sorted(traffic.items())) + "\n")
     mf = sorted(glob.glob(os.path.join(sess, "mfma", "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)
     if mf:
         acc, cnt, dur, seen = defaultdict(lambda: defaultdict(float)), defaultdict(int), defaultdict(float), set()
