@@ -1,8 +1,10 @@
 """Build libxvit_hip.so (gfx950 code objects + the C-ABI) in-tree with hipcc.
 
-    python cross-attention-vit_amd/build.py [--force]
+    python cross-attention-vit_amd/build.py [--force] [--out PATH] [-D MACRO ...]
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the tree.
+-D adds diagnostic macros (README "Diagnostic build macros"); such a build belongs in its own --out file (e.g.
+tools/_bin/libxvit_probe.so, loaded through XVIT_LIB) so that the product library stays the plain build.
 """
 from __future__ import annotations
 
@@ -25,15 +27,17 @@ def _deps_mtime():
     return max(os.path.getmtime(f) for f in files)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _deps_mtime():
-        return OUT
+def build(force: bool = False, verbose: bool = True, out: str = OUT, defines=()) -> str:
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= _deps_mtime():
+        return out
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    os.makedirs(OBJ, exist_ok=True)
+    obj_dir = OBJ if out == OUT else os.path.join(OBJ, os.path.basename(out) + ".d")
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
 
     def compile_one(src):
-        obj = os.path.join(OBJ, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
@@ -43,15 +47,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], capture_output=True, text=True)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(f"built {OUT} ({os.path.getsize(OUT) / 1e6:.1f} MB)")
-    return OUT
+        print(f"built {out} ({os.path.getsize(out) / 1e6:.1f} MB)")
+    return out
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
-    build(force=ap.parse_args().force)
+    ap.add_argument("--out", default=OUT)
+    ap.add_argument("-D", dest="defines", action="append", default=[])
+    a = ap.parse_args()
+    build(force=a.force or bool(a.defines), out=a.out, defines=a.defines)

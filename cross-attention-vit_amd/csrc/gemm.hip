@@ -782,10 +782,25 @@ __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, const f3
 // WIDE_ACT >= 0: the 16-byte-per-lane bf16 epilogue with that activation and no dropout, as its own instantiation (with
 // several fully unrolled epilogue variants behind one K loop the register allocator spills: one variant per kernel here;
 // the narrow kernels keep the run-time switch over activation x dropout and do not spill).  WIDE_ACT = -1: narrow.
+#ifdef XVIT_GEMM_CLOCK_PROBE
+// Diagnostic build (tools/gemm_kstep_probe.py): workgroup b < 4096 leaves its lifetime in shader cycles (clock64) and in
+// ticks of the constant 100 MHz counter (wall_clock64); their ratio is the clock the CU ran at under this kernel's load.
+__device__ long long xvit_dbg_clk[2 * 4096];
+struct ClockProbe {
+  long long c0, w0;
+  __device__ ClockProbe() : c0(clock64()), w0(wall_clock64()) {}
+  __device__ ~ClockProbe() {
+    if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.x < 4096) { xvit_dbg_clk[2 * blockIdx.x] = clock64() - c0; xvit_dbg_clk[2 * blockIdx.x + 1] = wall_clock64() - w0; }
+  }
+};
+#endif
 template <bool A_KS, bool B_KS, int WIDE_ACT>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
+#ifdef XVIT_GEMM_CLOCK_PROBE
+  ClockProbe clock_probe;
+#endif
   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;   // 2 x 4 waves
 
@@ -891,6 +906,7 @@ static std::atomic<int> g_gemm_group{0};     // xvit_set_option("gemm_group"): 0
 
 static bool use_big_tile(const xvit_gemm_args* a) {
   if (a->M < 256 || a->N < 256 || g_gemm_tile.load(std::memory_order_relaxed) == 1) return false;
+  if (g_gemm_tile.load(std::memory_order_relaxed) == 2) return true;   // diagnostics: the 256x256 kernel on grids of any size
   const int64_t big_blocks = (int64_t)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->batch * (a->split_k > 0 ? a->split_k : 1);
   return big_blocks > 128;
 }
@@ -898,7 +914,7 @@ static bool use_big_tile(const xvit_gemm_args* a) {
 extern "C" int xvit_set_option(const char* name, int value) {
   XVIT_REQUIRE(name != nullptr, "xvit_set_option: null name");
   const std::string n(name);
-  if (n == "gemm_tile") { XVIT_REQUIRE(value == 0 || value == 1, "xvit_set_option: gemm_tile must be 0 (auto) or 1 (128x128 only)"); g_gemm_tile = value; return 0; }
+  if (n == "gemm_tile") { XVIT_REQUIRE(value >= 0 && value <= 2, "xvit_set_option: gemm_tile must be 0 (auto), 1 (128x128 only) or 2 (256x256 whenever M, N >= 256)"); g_gemm_tile = value; return 0; }
   if (n == "gemm_group") { XVIT_REQUIRE(value >= 0 && value <= 4096, "xvit_set_option: gemm_group must be in [0, 4096]"); g_gemm_group = value; return 0; }
   if (n == "gemm_epilogue") { XVIT_REQUIRE(value == 0 || value == 1, "xvit_set_option: gemm_epilogue must be 0 (auto) or 1 (narrow)"); g_gemm_epi = value; return 0; }
   set_error("xvit_set_option: unknown option '%s'", name);
@@ -1011,3 +1027,7 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   }
   return check_launch("xvit_gemm");
 }
+
+#ifdef XVIT_GEMM_CLOCK_PROBE
+extern "C" int xvit_dbg_read_clk(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(xvit::xvit_dbg_clk), (size_t)n * 16); }
+#endif

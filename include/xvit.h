@@ -36,7 +36,7 @@ typedef void* xvit_stream_t; /* hipStream_t */
 int xvit_version(void);
 const char* xvit_last_error_string(void);
 /* Process-wide tuning knobs (diagnostics / A-B measurements; results never depend on them):
- *   "gemm_tile"      0 = automatic tile choice, 1 = always the 128x128 kernel
+ *   "gemm_tile"      0 = automatic tile choice, 1 = always the 128x128 kernel, 2 = the 256x256 kernel whenever M, N >= 256
  *   "gemm_group"     0 = automatic, n > 0 = column tiles per super-column of the 256x256 kernel's tile walk
  *   "gemm_epilogue"  0 = automatic, 1 = always the 8-byte-per-lane epilogue (bf16 outputs normally use 16 bytes per lane) */
 int xvit_set_option(const char* name, int value);
