@@ -325,6 +325,7 @@ struct BigLoader {
 
 // NT = number of 16-wide tiles this wave reads from the image (8 along M, 4 along N);
 // `first` = index of the wave's first 16-wide tile inside the 256-wide image.
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_dbg;
 template <bool KS, int NT_>
 struct BigFrag {
   uint32_t off[KS ? 2 * NT_ : 2];
@@ -346,6 +347,12 @@ struct BigFrag {
     }
   }
   __device__ __forceinline__ bf16x8 read(const XVIT_LDS char* image, int t, int kk) const {
+#ifdef XVIT_DEBUG_NO_LDSREAD   // energy decomposition: MFMAs on register-resident pseudo-random operands, no fragment reads
+    u32x4_dbg v = {off[0] * 2654435761u, off[0] * 40503u + 12345u, (uint32_t)t * 0x9E3779B9u ^ off[0], 0x3F803F80u ^ (off[0] << 3)};
+    v &= 0xBFFFBFFFu;            // keep the bf16 exponents below 2^1: finite products
+    asm volatile("" : "+v"(v));
+    return __builtin_bit_cast(bf16x8, v);
+#endif
     if (KS) {
       const s16x4 lo = lds_read_tr16(image + off[t * 2 + 0] + kk * 32 * 512);
       const s16x4 hi = lds_read_tr16(image + off[t * 2 + 1] + kk * 32 * 512);
