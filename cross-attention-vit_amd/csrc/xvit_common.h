@@ -62,9 +62,12 @@ __device__ __forceinline__ uint32_t clamp_bytes(int64_t b) {
 // simply not model these loads.  Untracked VMEM ops can only make the compiler's own vmcnt waits
 // stricter, never weaker (the counter retires in order).  lds_base, soff and r must be wave-uniform.
 // M0 is written in the same statement that consumes it; nothing else in these kernels uses M0.
+#ifndef XVIT_GLDS_POLICY
+#define XVIT_GLDS_POLICY ""      // cache-policy modifiers of the LDS-DMA loads (" nt", " sc1", ...): A/B builds only
+#endif
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t r, XVIT_LDS void* lds_base, uint32_t voff, uint32_t soff) {
   const uint32_t m0v = (uint32_t)(uintptr_t)lds_base;
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen" XVIT_GLDS_POLICY " lds"
                :
                : "v"(voff), "s"(r), "s"(soff), "s"(m0v)
                : "memory");
