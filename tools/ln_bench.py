@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of LayerNorm fwd/bwd at the model's shape (HIP-event timed)."""
+"""LayerNorm forward / backward at the step's shapes (rows = 126 x 513, d = 768), GB/s of algorithmic bytes.
+    [XVIT_LIB=other.so] python tools/ln_bench.py"""
 import os
 import sys
 
@@ -9,33 +10,30 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cross-attention-vit_amd"))
 from xvit import ops  # noqa: E402
 
+dev = torch.device("cuda:0")
+rows, d = 126 * 513, 768
+x = torch.randn(rows, d, device=dev)
+g, b = torch.randn(d, device=dev), torch.randn(d, device=dev)
+dy = torch.randn(rows, d, device=dev).bfloat16()
+dres = torch.randn(rows, d, device=dev)
 
-def timeit(fn, n=30):
+
+def timed(fn, reps=30):
     for _ in range(3):
         fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(n):
+    for _ in range(reps):
         fn()
-    e.record()
-    torch.cuda.synchronize()
-    return s.elapsed_time(e) / n * 1e3
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps * 1e3
 
 
-def main():
-    dev = torch.device("cuda:0")
-    for rows, d in [(42 * 513, 768), (32 * 513, 768)]:
-        x = torch.randn(rows, d, device=dev)
-        g, b = torch.ones(d, device=dev), torch.zeros(d, device=dev)
-        dy = torch.randn(rows, d, device=dev).bfloat16()
-        dres = torch.randn(rows, d, device=dev)
-        y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5)
-        acc = torch.zeros(4 * d, device=dev)
-        a0, a1, a2, a3 = acc.split(d)
-        us_f = timeit(lambda: ops.layernorm_fwd(x, g, b, 1e-5))
-        us_b = timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, a0, a1, dres=dres, want_bf16=True, dxsum=a2, dressum=a3))
-        print(f"LN rows={rows} d={d}: fwd {us_f:6.1f} us {rows * d * 6 / us_f / 1e3:7.1f} GB/s | bwd {us_b:6.1f} us {rows * d * 16 / us_b / 1e3:7.1f} GB/s", flush=True)
-
-
-if __name__ == "__main__":
-    main()
+y, mean, rstd = ops.layernorm_fwd(x, g, b, 1e-5)
+us = timed(lambda: ops.layernorm_fwd(x, g, b, 1e-5))
+print(f"ln_fwd           {us:7.1f} us  {rows * d * 6 / us / 1e3:7.0f} GB/s")
+dg, db, s1, s2 = (torch.zeros(d, device=dev) for _ in range(4))
+for name, kw, bytes_per in (("ln_bwd (LN1: dres)", dict(dres=dres), 14), ("ln_bwd (LN2: dres, bf16 copy, 2 sums)", dict(dres=dres, want_bf16=True, dxsum=s1, dressum=s2), 16),
+                            ("ln_bwd (no dres)", dict(), 10)):
+    us = timed(lambda: ops.layernorm_bwd(dy, x, mean, rstd, g, dg, db, **kw))
+    print(f"{name:40s} {us:7.1f} us  {rows * d * bytes_per / us / 1e3:7.0f} GB/s")
