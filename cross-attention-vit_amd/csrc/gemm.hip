@@ -30,7 +30,36 @@ struct GemmParams {
   float drop_p, drop_inv; uint64_t drop_seed;   // dropout after the activation, before the residual (p == 0: off)
   int narrow_epi;                // force the 8-byte-per-lane epilogue (A/B measurements)
   int ncg;                       // gemm_big_kernel: column tiles per super-column of the tile walk
+  // Patch rows gathered straight from the volume (xvit_patch_embed_*; reference model_cross.py:193, the einops rearrange
+  // 'b c (d p1) (h p2) (w p3) -> b (h w d) (p1 p2 p3 c)' in front of patch_to_embedding): the [rows, dp hp wp] patch matrix is
+  // never stored.  mode 1: the A rows of the forward NT product; mode 2: the weight gradient (TN), whose contraction runs over
+  // the patch rows in token order with the CLS rows skipped, so both operands take their K-step offset from (sample, 64-token group).
+  struct PatchGather {
+    int mode;
+    int dp, hp, wp;        // patch extents along the volume's first / middle / contiguous axis
+    int Dn, Wn;            // patches along the first and the contiguous axis: token t = (h Wn + w) Dn + d
+    int Sy, Sz;            // element strides of the middle and the first axis (W, H W)
+    int pcount, ntok, cls; // patches per sample, rows per sample in the token matrix (cls + pcount), leading CLS rows (0 | 1)
+    int nb;                // samples are ordered [modality][batch]: s -> modality s / nb, batch s % nb
+    int64_t sBt, sMd;      // element strides of batch and modality in the volume tensor
+    uint32_t vol_bytes;
+  } g;
 };
+
+// ---- patch-gather address arithmetic (elements; every volume stays below 2 GiB, so byte offsets fit 31 bits) -------------
+constexpr uint32_t GATHER_OOB = 0x80000000u;   // + any K-step offset < 2^31 neither wraps nor falls below num_records
+__device__ __forceinline__ uint32_t gather_elem_off(const GemmParams::PatchGather& g, int e) {   // feature f = (p1 hp + p2) wp + p3
+  const int hw = g.hp * g.wp, p1 = e / hw, r = e - p1 * hw, p2 = r / g.wp, p3 = r - p2 * g.wp;
+  return (uint32_t)(p1 * g.Sz + p2 * g.Sy + p3);
+}
+__device__ __forceinline__ uint32_t gather_patch_origin(const GemmParams::PatchGather& g, int q) {   // token q of a sample
+  const int d = q % g.Dn, t = q / g.Dn, w = t % g.Wn, h = t / g.Wn;
+  return (uint32_t)(d * g.dp * g.Sz + h * g.hp * g.Sy + w * g.wp);
+}
+__device__ __forceinline__ uint32_t gather_sample_origin(const GemmParams::PatchGather& g, int s) {
+  const int mod = s / g.nb, b = s - mod * g.nb;
+  return (uint32_t)(b * g.sBt + mod * g.sMd);
+}
 
 // ---- the fused epilogue, shared by both tile kernels and the split-K reduce kernel -------------
 // v: 4 consecutive output columns of one row (fp32 accumulators).  Returns the value stored.
@@ -316,12 +345,47 @@ struct BigLoader {
     }
     kstep = KS ? (uint32_t)(BK * ld * 2) : (uint32_t)(BK * 2);
   }
-  __device__ __forceinline__ void issue(XVIT_LDS char* image, int wave, int kt) const {
-    const uint32_t soff = (uint32_t)kt * kstep;
+  // mode 1 (KS = false): row m0 + r of the token matrix = patch (sample, token) or a CLS / out-of-range row (zeros)
+  __device__ __forceinline__ void init_gather_rows(const GemmParams::PatchGather& g, const bf16* vol, int m0, int M, int wave, int lane) {
+    rsrc = make_rsrc(vol, g.vol_bytes);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rl = (wave * 4 + j) * 8 + (lane >> 3), row = m0 + rl;
+      const int chunk = (lane & 7) ^ swz_kc(rl);
+      const int smp = row / g.ntok, n = row - smp * g.ntok;
+      voff[j] = (row < M && n >= g.cls) ? 2u * (gather_sample_origin(g, smp) + gather_patch_origin(g, n - g.cls) + gather_elem_off(g, chunk * 8)) : GATHER_OOB;
+    }
+    kstep = 0;
+  }
+  // mode 2 (KS = true): k-row = token (64 consecutive tokens of one sample per K-step), column = feature n0 + c
+  __device__ __forceinline__ void init_gather_ks(const GemmParams::PatchGather& g, const bf16* vol, int n0, int N, int wave, int lane) {
+    rsrc = make_rsrc(vol, g.vol_bytes);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int krow = (wave * 4 + j) * 2 + (lane >> 5);
+      const int e = n0 + (((lane & 31) ^ swz_ks(krow)) << 3);
+      voff[j] = e < N ? 2u * ((uint32_t)((krow % g.Dn) * g.dp * g.Sz + (krow / g.Dn) * g.wp) + gather_elem_off(g, e)) : GATHER_OOB;
+    }
+    kstep = 0;
+  }
+  __device__ __forceinline__ void issue_at(XVIT_LDS char* image, int wave, uint32_t soff) const {
 #pragma unroll
     for (int j = 0; j < 4; ++j) glds16(rsrc, image + (wave * 4 + j) * 1024, voff[j], soff);
   }
+  __device__ __forceinline__ void issue(XVIT_LDS char* image, int wave, int kt) const { issue_at(image, wave, (uint32_t)kt * kstep); }
 };
+
+// K-step offsets (bytes) of the gathered operands; ktg = K-step index counted from k = 0
+__device__ __forceinline__ uint32_t gather_soff_rows(const GemmParams::PatchGather& g, int ktg) { return 2u * gather_elem_off(g, ktg * 64); }
+struct GatherStep { uint32_t a, b; };
+__device__ __forceinline__ GatherStep gather_soff_wgrad(const GemmParams::PatchGather& g, int ktg, int64_t lda) {
+  const int spk = g.pcount >> 6, smp = ktg / spk, r = ktg - smp * spk;     // 64-token group r of sample smp
+  const int wsteps = (g.Dn * g.Wn) >> 6, h = r / wsteps, wpart = (r - h * wsteps) * (64 / g.Dn);
+  GatherStep o;
+  o.a = (uint32_t)(((int64_t)smp * g.ntok + g.cls + r * 64) * lda * 2);
+  o.b = 2u * (gather_sample_origin(g, smp) + (uint32_t)(h * g.hp * g.Sy + wpart * g.wp));
+  return o;
+}
 
 // NT = number of 16-wide tiles this wave reads from the image (8 along M, 4 along N);
 // `first` = index of the wave's first 16-wide tile inside the 256-wide image.
@@ -801,7 +865,7 @@ struct ClockProbe {
   }
 };
 #endif
-template <bool A_KS, bool B_KS, int WIDE_ACT>
+template <bool A_KS, bool B_KS, int WIDE_ACT, int GATHER = 0>
 __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
@@ -838,12 +902,24 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   BigLoader<B_KS> lb;
   {
     const bf16* Ab = p.A + batch * p.sA;
-    if (A_KS) la.init(Ab + (int64_t)k_begin * p.lda + m0, ((int64_t)(k_end - 1 - k_begin) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane);
+    if constexpr (GATHER == 1) la.init_gather_rows(p.g, Ab, m0, p.M, wave, lane);
+    else if constexpr (GATHER == 2) {   // dY rows are re-indexed per K-step (CLS rows skipped): base = row 0, K-step offsets from gather_soff_wgrad
+      const int64_t rows = (int64_t)(p.K / p.g.pcount) * p.g.ntok;
+      la.init(Ab + m0, ((rows - 1) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane);
+    } else if (A_KS) la.init(Ab + (int64_t)k_begin * p.lda + m0, ((int64_t)(k_end - 1 - k_begin) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane);
     else la.init(Ab + (int64_t)m0 * p.lda + k_begin, ((int64_t)(p.M - 1 - m0) * p.lda + (k_end - k_begin)) * 2, p.lda, wave, lane);
     const bf16* Bb = p.B + batch * p.sB;
-    if (B_KS) lb.init(Bb + (int64_t)k_begin * p.ldb + n0, ((int64_t)(k_end - 1 - k_begin) * p.ldb + (p.N - n0)) * 2, p.ldb, wave, lane);
+    if constexpr (GATHER == 2) lb.init_gather_ks(p.g, Bb, n0, p.N, wave, lane);
+    else if (B_KS) lb.init(Bb + (int64_t)k_begin * p.ldb + n0, ((int64_t)(k_end - 1 - k_begin) * p.ldb + (p.N - n0)) * 2, p.ldb, wave, lane);
     else lb.init(Bb + (int64_t)n0 * p.ldb + k_begin, ((int64_t)(p.N - 1 - n0) * p.ldb + (k_end - k_begin)) * 2, p.ldb, wave, lane);
   }
+  // byte offsets of K-step kt (relative to this split's first) for the two loaders
+  const int ktg0 = k_begin / BK;
+  auto step_off = [&](int kt, uint32_t& oa, uint32_t& ob) {
+    if constexpr (GATHER == 1) { oa = gather_soff_rows(p.g, ktg0 + kt); ob = (uint32_t)kt * lb.kstep; }
+    else if constexpr (GATHER == 2) { GatherStep o; o = gather_soff_wgrad(p.g, ktg0 + kt, p.lda); oa = o.a; ob = o.b; }
+    else { oa = (uint32_t)kt * la.kstep; ob = (uint32_t)kt * lb.kstep; }
+  };
   BigFrag<A_KS, 8> fa;
   BigFrag<B_KS, 4> fb;
   fa.init(wr * 8, lane);
@@ -857,19 +933,22 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
 
   const __amdgpu_buffer_rsrc_t null_rsrc = make_rsrc(p.A, 0u);   // every access out of range: the DMA fills zeros, fetches nothing
   if (nk > 0) {
-    la.issue(smem, wave, 0);
-    lb.issue(smem + T_OPER, wave, 0);
+    uint32_t oa, ob;
+    step_off(0, oa, ob);
+    la.issue_at(smem, wave, oa);
+    lb.issue_at(smem + T_OPER, wave, ob);
   }
   for (int kt = 0; kt < nk; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool more = kt + 1 < nk;
+    uint32_t soff_a, soff_b;
+    step_off(kt + 1, soff_a, soff_b);
     XVIT_LDS char* nxt = smem + ((kt + 1) & 1) * T_STAGE;
     const XVIT_LDS char* sa = smem + (kt & 1) * T_STAGE;
     const XVIT_LDS char* sb = sa + T_OPER;
 #ifndef XVIT_DEBUG_NO_MMA
-    big_tile_mma<A_KS, B_KS>(sa, sb, fa, fb, acc, la, lb, more ? la.rsrc : null_rsrc, more ? lb.rsrc : null_rsrc, nxt, wave,
-                             (uint32_t)(kt + 1) * la.kstep, (uint32_t)(kt + 1) * lb.kstep);
+    big_tile_mma<A_KS, B_KS>(sa, sb, fa, fb, acc, la, lb, more ? la.rsrc : null_rsrc, more ? lb.rsrc : null_rsrc, nxt, wave, soff_a, soff_b);
 #endif
   }
 
@@ -983,6 +1062,7 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
   p.narrow_epi = g_gemm_epi.load(std::memory_order_relaxed);
   p.ncg = 1;
+  p.g.mode = 0;
   hipStream_t s = (hipStream_t)stream;
 
   static std::once_flag attr_once;   // the library is re-entrant: concurrent first calls from several host threads
@@ -1033,6 +1113,130 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(g), dim3(256), 0, s, p, a->batch);
   }
   return check_launch("xvit_gemm");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Patch embedding straight from the volume (reference model_cross.py:193-197): the [rows, dp hp wp] patch matrix of the
+// einops rearrange is never written — gemm_big_kernel's LDS-DMA loaders gather the 16-byte chunks of every patch row from
+// the [B, M, 1, D, H, W] bf16 tensor (a 64-deep K-step of one patch row = 64 / wp runs of wp contiguous voxels).
+// ------------------------------------------------------------------------------------------------------------------
+static int64_t pe_rows(const xvit_patch_geom* g) {
+  return (int64_t)g->M * g->B * (g->cls_rows + (int64_t)(g->D / g->dp) * (g->H / g->hp) * (g->W / g->wp));
+}
+
+extern "C" int xvit_patch_embed_supported(const xvit_patch_geom* g, int d) {
+  if (!g || g->B <= 0 || g->M <= 0 || g->dp <= 0 || g->hp <= 0 || g->wp <= 0 || (g->cls_rows != 0 && g->cls_rows != 1)) return 0;
+  if (g->D % g->dp || g->H % g->hp || g->W % g->wp) return 0;
+  const int Dn = g->D / g->dp, Hn = g->H / g->hp, Wn = g->W / g->wp;
+  const int64_t pd = (int64_t)g->dp * g->hp * g->wp, pcount = (int64_t)Dn * Hn * Wn;
+  if (g->wp % 8 || 64 % g->wp || (g->hp * g->wp) % 64) return 0;          // a K-step = whole runs of one (p1) slab
+  if (64 % Dn || (Dn * Wn) % 64) return 0;                                  // 64 consecutive tokens = whole d-columns of one h
+  if (pd % 256 || d % 256 || d < 256) return 0;                            // full 256-wide tiles on both outputs
+  const int64_t rows = pe_rows(g);
+  if (rows < 2048) return 0;                                               // small problems: the 128x128 kernels on a stored patch matrix
+  if ((int64_t)g->B * g->M * g->D * g->H * g->W * 2 >= (1ll << 31)) return 0;
+  if (rows * d * 4 >= (1ll << 31) || pcount > (1 << 24)) return 0;
+  return 1;
+}
+
+static void pe_fill(GemmParams& p, const xvit_patch_geom* g, int mode) {
+  p.g.mode = mode;
+  p.g.dp = g->dp; p.g.hp = g->hp; p.g.wp = g->wp;
+  p.g.Dn = g->D / g->dp; p.g.Wn = g->W / g->wp;
+  p.g.Sy = g->W; p.g.Sz = g->H * g->W;
+  p.g.pcount = (g->D / g->dp) * (g->H / g->hp) * (g->W / g->wp);
+  p.g.cls = g->cls_rows; p.g.ntok = p.g.cls + p.g.pcount;
+  p.g.nb = g->B;
+  p.g.sMd = (int64_t)g->D * g->H * g->W; p.g.sBt = p.g.sMd * g->M;
+  p.g.vol_bytes = (uint32_t)((int64_t)g->B * g->M * g->D * g->H * g->W * 2);
+}
+
+static void pe_defaults(GemmParams& p) {
+  p.bias = nullptr; p.res = nullptr; p.aux = nullptr; p.slab = nullptr; p.colsum = nullptr;
+  p.lda = p.ldb = p.ldc = p.ldr = p.ldaux = 0;
+  p.sA = p.sB = p.sC = p.sBias = p.sR = p.sAux = 0;
+  p.c_f32 = 1; p.act = XVIT_ACT_NONE; p.accumulate = 0;
+  p.res_row_mod = 0; p.res_row_off = 0; p.seg_rows = 0; p.seg_skip = 0; p.row_off = 0;
+  p.drop_p = 0.f; p.drop_inv = 1.f; p.drop_seed = 0; p.narrow_epi = 1; p.split_k = 1;
+}
+
+static void pe_attrs() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, -1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, -1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+  });
+}
+
+extern "C" int xvit_patch_embed_fwd(const void* img, const xvit_patch_geom* g, const void* W, int64_t ldw, const float* bias, const float* pos, int64_t ldpos,
+                                    float* x, int64_t ldx, int d, xvit_stream_t stream) {
+  XVIT_REQUIRE(img && g && W && x, "xvit_patch_embed_fwd: null pointer");
+  XVIT_REQUIRE(xvit_patch_embed_supported(g, d) == 1, "xvit_patch_embed_fwd: geometry not supported by the fused kernel (xvit_patch_embed_supported)");
+  const int64_t pd = (int64_t)g->dp * g->hp * g->wp;
+  XVIT_REQUIRE(ldw >= pd && ldw % 8 == 0 && ldx >= d && ldx % 4 == 0 && (!pos || (ldpos >= d && ldpos % 4 == 0)), "xvit_patch_embed_fwd: bad leading dimension");
+  XVIT_REQUIRE(aligned16(img) && aligned16(W) && aligned16(x) && (!bias || aligned16(bias)) && (!pos || aligned16(pos)), "xvit_patch_embed_fwd: pointers must be 16-byte aligned");
+  GemmParams p;
+  pe_defaults(p);
+  pe_fill(p, g, 1);
+  p.A = (const bf16*)img; p.B = (const bf16*)W; p.C = x; p.bias = bias; p.res = pos;
+  p.ldb = ldw; p.ldc = ldx; p.ldr = ldpos;
+  p.M = (int)pe_rows(g); p.N = d; p.K = (int)pd;
+  p.k_per_split = p.K;
+  if (pos) { p.res_row_mod = p.g.ntok; p.res_row_off = 0; }   // x row (s, n) += pos[n]  (model_cross.py:197)
+  p.ntm = (p.M + TBM - 1) / TBM; p.ntn = (p.N + TBN - 1) / TBN; p.ncg = p.ntn;
+  pe_attrs();
+  hipLaunchKernelGGL((gemm_big_kernel<false, false, -1, 1>), dim3(p.ntm * p.ntn, 1, 1), dim3(512), T_LDS, (hipStream_t)stream, p);
+  return check_launch("xvit_patch_embed_fwd");
+}
+
+static int pe_wgrad_split(const xvit_patch_geom* g, int d) {
+  const int64_t pd = (int64_t)g->dp * g->hp * g->wp;
+  const int tiles = (int)((d / 256) * (pd / 256));
+  const int64_t ksteps = pe_rows(g) / 64;   // ~ contraction length / 64
+  int split = 256 / (tiles > 0 ? tiles : 1);
+  if (split > ksteps / 8) split = (int)(ksteps / 8);
+  if (split > 16) split = 16;
+  return split < 1 ? 1 : split;
+}
+
+extern "C" int64_t xvit_patch_embed_wgrad_workspace_bytes(const xvit_patch_geom* g, int d) {
+  if (!g || xvit_patch_embed_supported(g, d) != 1) return 0;
+  const int split = pe_wgrad_split(g, d);
+  return split > 1 ? (int64_t)split * d * g->dp * g->hp * g->wp * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int xvit_patch_embed_wgrad(const void* img, const xvit_patch_geom* g, const void* dx, int64_t lddx, float* dW, int64_t lddw, int d, void* workspace,
+                                      int64_t workspace_bytes, xvit_stream_t stream) {
+  XVIT_REQUIRE(img && g && dx && dW, "xvit_patch_embed_wgrad: null pointer");
+  XVIT_REQUIRE(xvit_patch_embed_supported(g, d) == 1, "xvit_patch_embed_wgrad: geometry not supported by the fused kernel (xvit_patch_embed_supported)");
+  const int64_t pd = (int64_t)g->dp * g->hp * g->wp;
+  XVIT_REQUIRE(lddx >= d && lddx % 8 == 0 && lddw >= pd && lddw % 4 == 0, "xvit_patch_embed_wgrad: bad leading dimension");
+  XVIT_REQUIRE(aligned16(img) && aligned16(dx) && aligned16(dW), "xvit_patch_embed_wgrad: pointers must be 16-byte aligned");
+  XVIT_REQUIRE(pe_rows(g) * lddx * 2 < (1ll << 31), "xvit_patch_embed_wgrad: dx exceeds 2 GiB (unsupported addressing range)");
+  const int64_t need = xvit_patch_embed_wgrad_workspace_bytes(g, d);
+  XVIT_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && aligned16(workspace)), "xvit_patch_embed_wgrad: needs %lld bytes of 16-byte aligned workspace (got %lld)",
+               (long long)need, (long long)workspace_bytes);
+  GemmParams p;
+  pe_defaults(p);
+  pe_fill(p, g, 2);
+  p.A = (const bf16*)dx; p.B = (const bf16*)img; p.C = dW;
+  p.lda = lddx; p.ldc = lddw;
+  p.M = d; p.N = (int)pd;
+  p.K = (int)((int64_t)g->M * g->B * p.g.pcount);          // contraction over the patch rows; CLS rows carry no patch
+  p.split_k = pe_wgrad_split(g, d);
+  const int ktiles = p.K / BK;
+  p.k_per_split = ((ktiles + p.split_k - 1) / p.split_k) * BK;
+  p.slab = need > 0 ? (float*)workspace : nullptr;
+  p.ntm = (p.M + TBM - 1) / TBM; p.ntn = (p.N + TBN - 1) / TBN; p.ncg = p.ntn;
+  pe_attrs();
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL((gemm_big_kernel<true, true, -1, 2>), dim3(p.ntm * p.ntn, 1, p.split_k), dim3(512), T_LDS, s, p);
+  if (p.slab) {
+    const int64_t work = (int64_t)p.M * (p.N / 4);
+    const int gsz = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(gsz), dim3(256), 0, s, p, 1);
+  }
+  return check_launch("xvit_patch_embed_wgrad");
 }
 
 #ifdef XVIT_GEMM_CLOCK_PROBE

@@ -23,6 +23,11 @@ class GemmArgs(C.Structure):
         ("workspace", vp), ("workspace_bytes", i64), ("colsum", vp), ("dropout_p", f32), ("reserved2", i32), ("dropout_seed", u64)]
 
 
+class PatchGeom(C.Structure):
+    """struct xvit_patch_geom (include/xvit.h)."""
+    _fields_ = [(n, i32) for n in ("B", "M", "D", "H", "W", "dp", "hp", "wp", "cls_rows")]
+
+
 # name -> argtypes; every function returns int except the two noted below
 SIGNATURES = {
     "xvit_gemm": [C.POINTER(GemmArgs), vp],
@@ -36,6 +41,9 @@ SIGNATURES = {
     "xvit_cls_xattn_fwd": [vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, i32, i64, vp],
+    "xvit_patch_embed_supported": [C.POINTER(PatchGeom), i32],
+    "xvit_patch_embed_fwd": [vp, C.POINTER(PatchGeom), vp, i64, vp, vp, i64, vp, i64, i32, vp],
+    "xvit_patch_embed_wgrad": [vp, C.POINTER(PatchGeom), vp, i64, vp, i64, i32, vp, i64, vp],
     "xvit_cls_row_fwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_embed_bwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_cast_f32_bf16": [vp, vp, i64, vp],
@@ -49,7 +57,7 @@ SIGNATURES = {
     "xvit_adam_step": [vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string", "xvit_gemm_workspace_bytes", "xvit_linear_f32_workspace_bytes",
-                                    "xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes"])
+                                    "xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes", "xvit_patch_embed_wgrad_workspace_bytes"])
 
 _lib = None
 
@@ -73,6 +81,8 @@ def load() -> C.CDLL:
         for name in ("xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes"):
             getattr(lib, name).argtypes = [i32, i32]
             getattr(lib, name).restype = C.c_int64
+        lib.xvit_patch_embed_wgrad_workspace_bytes.argtypes = [C.POINTER(PatchGeom), i32]
+        lib.xvit_patch_embed_wgrad_workspace_bytes.restype = C.c_int64
         lib.xvit_version.restype = C.c_int
         lib.xvit_last_error_string.restype = C.c_char_p
         _lib = lib

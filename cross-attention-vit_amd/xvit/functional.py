@@ -506,22 +506,32 @@ class PatchEmbedFn(Function):
     def forward(ctx, img, w, b, cls, pos, patch, p=0.0, concat=False):
         Bn, M = img.shape[0], img.shape[1]
         d, pd = w.shape
-        if concat:   # ModelVIT (modelv3.py:123-137): one sequence per sample, cls + the patches of every modality
-            patches = ops.patchify(img.contiguous(), patch, concat=True)                    # [B*(M*P+1), pd]
-            M = 1
-        else:        # ModelCross (model_cross.py:191-199): one sequence per (modality, sample)
-            patches = ops.patchify(img.contiguous(), patch, pad_cls_row=True).reshape(-1, pd)   # [M*B*N, pd], row 0 of each sample = 0
-        N = patches.shape[0] // (M * Bn)
         w_s = SHADOWS.get(w)
-        pos2 = pos.detach().reshape(N, d)
-        x = torch.empty(M * Bn * N, d, dtype=torch.float32, device=img.device)
-        ops.gemm(ops.NT, patches, w_s, x, bias=b, residual=pos2, res_row_mod=N, res_row_off=0)
+        # a bf16 volume tensor feeds the GEMM's loaders directly (no [rows, pd] patch matrix in HBM: -2 GB of traffic and
+        # -1 GB resident per step at configs[1]); other inputs (fp32 volumes, ModelVIT's concatenated sequence, small or odd
+        # geometries) go through the patchify kernel, which also converts
+        fused = not concat and ops.patch_embed_supported(img, patch, d, cls_rows=1)
+        if fused:
+            N = 1 + (img.shape[3] // patch[0]) * (img.shape[4] // patch[1]) * (img.shape[5] // patch[2])
+            pos2 = pos.detach().reshape(N, d)
+            x = ops.patch_embed_fwd(img, patch, w_s, b, pos2, cls_rows=1)
+            patches = img
+        else:
+            if concat:   # ModelVIT (modelv3.py:123-137): one sequence per sample, cls + the patches of every modality
+                patches = ops.patchify(img.contiguous(), patch, concat=True)                    # [B*(M*P+1), pd]
+                M = 1
+            else:        # ModelCross (model_cross.py:191-199): one sequence per (modality, sample)
+                patches = ops.patchify(img.contiguous(), patch, pad_cls_row=True).reshape(-1, pd)   # [M*B*N, pd], row 0 of each sample = 0
+            N = patches.shape[0] // (M * Bn)
+            pos2 = pos.detach().reshape(N, d)
+            x = torch.empty(M * Bn * N, d, dtype=torch.float32, device=img.device)
+            ops.gemm(ops.NT, patches, w_s, x, bias=b, residual=pos2, res_row_mod=N, res_row_off=0)
         ops.cls_row_fwd(cls.detach().reshape(d), pos2, x, M * Bn, N, d)
         seed = drop_seeds(1)[0] if p > 0.0 else 0
         if p > 0.0:                       # self.dropout on the embedded tokens (model_cross.py:198)
             ops.dropout(x, p, seed, out=x)
-        ctx.meta = (M, Bn, N, d, p, seed)
-        ctx.save_for_backward(patches)
+        ctx.meta = (M, Bn, N, d, p, seed, patch if fused else None)
+        ctx.save_for_backward(patches)     # fused: the volume tensor itself
         if concat:
             return x.reshape(Bn, N, d)
         # one output per modality (views of one buffer): slicing a stacked [M, B, N, d] output in the caller would cost
@@ -530,7 +540,7 @@ class PatchEmbedFn(Function):
 
     @staticmethod
     def backward(ctx, *dxs):
-        M, Bn, N, d, p, seed = ctx.meta
+        M, Bn, N, d, p, seed, fused_patch = ctx.meta
         (patches,) = ctx.saved_tensors
         dev = patches.device
         dpos = torch.zeros(N, d, dtype=torch.float32, device=dev)
@@ -548,7 +558,10 @@ class PatchEmbedFn(Function):
                 g2 = _f32c(g).reshape(Bn * N, d)
                 ops.cast_bf16(g2, dxb[m * Bn * N:(m + 1) * Bn * N])
                 ops.embed_bwd(g2, dpos, dcls, Bn, N, d)      # accumulates into dpos / dcls
-        dW = _wgrad(dxb, patches)            # the zero CLS rows of `patches` drop the CLS-row gradients
+        if fused_patch is not None:
+            dW = ops.patch_embed_wgrad(patches, fused_patch, dxb, cls_rows=1)     # contraction over the patch rows only
+        else:
+            dW = _wgrad(dxb, patches)        # the zero CLS rows of `patches` drop the CLS-row gradients
         db = ops.colsum(dpos[1:])            # bias reaches the P patch rows of every sample
         _join_wgrads(dev)
         return None, dW, db, dcls.reshape(1, 1, d), dpos.reshape(1, N, d), None, None, None

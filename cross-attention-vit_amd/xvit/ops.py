@@ -299,6 +299,59 @@ def patchify(img, patch, pad_cls_row=False, concat=False):
     return out
 
 
+def _patch_geom(img, patch, cls_rows):
+    B, M, _, D, H, W = img.shape
+    g = _lib.PatchGeom()
+    g.B, g.M, g.D, g.H, g.W = B, M, D, H, W
+    g.dp, g.hp, g.wp = patch
+    g.cls_rows = int(cls_rows)
+    return g
+
+
+def patch_embed_supported(img, patch, d, cls_rows=1):
+    """True when the fused gather kernels (xvit_patch_embed_*) take this input: a contiguous bf16 [B, M, 1, D, H, W] volume
+    tensor and a geometry xvit_patch_embed_supported accepts (include/xvit.h).  XVIT_PATCH_EMBED=unfused forces the
+    patchify + GEMM path (A/B measurements)."""
+    if os.environ.get("XVIT_PATCH_EMBED", "fused") == "unfused":
+        return False
+    if img.dim() != 6 or img.shape[2] != 1 or img.dtype != torch.bfloat16 or not img.is_contiguous() or not img.is_cuda:
+        return False
+    return _lib.load().xvit_patch_embed_supported(C.byref(_patch_geom(img, patch, cls_rows)), int(d)) == 1
+
+
+def patch_embed_fwd(img, patch, w_b, bias, pos, cls_rows=1):
+    """x [M*B*(cls_rows + P), d] fp32 = patches(img) W^T + bias + pos[token], the patch matrix never stored
+    (model_cross.py:193-197).  w_b: bf16 [d, pd]; pos: fp32 [cls_rows + P, d] or None."""
+    g = _patch_geom(img, patch, cls_rows)
+    B, M, _, D, H, W = img.shape
+    P, pd = (D // patch[0]) * (H // patch[1]) * (W // patch[2]), patch[0] * patch[1] * patch[2]
+    d = w_b.shape[0]
+    assert w_b.dtype == torch.bfloat16 and w_b.shape[1] == pd and (pos is None or pos.shape == (cls_rows + P, d))
+    rows = M * B * (cls_rows + P)
+    x = torch.empty(rows, d, dtype=torch.float32, device=img.device)
+    _run("gemm_big_nt", 2.0 * M * B * P * d * pd, "flop",
+         lambda: _lib.load().xvit_patch_embed_fwd(_ptr(img), C.byref(g), _ptr(w_b), w_b.stride(0), _ptr(bias) if bias is not None else None,
+                                                  _ptr(pos) if pos is not None else None, pos.stride(0) if pos is not None else 0, _ptr(x), x.stride(0), d, _stream()),
+         "xvit_patch_embed_fwd")
+    return x
+
+
+def patch_embed_wgrad(img, patch, dx_b, cls_rows=1):
+    """dW [d, pd] fp32 = sum over patch rows of dx[row]^T patch(row); dx_b: bf16 [M*B*(cls_rows + P), d]."""
+    g = _patch_geom(img, patch, cls_rows)
+    B, M, _, D, H, W = img.shape
+    P, pd = (D // patch[0]) * (H // patch[1]) * (W // patch[2]), patch[0] * patch[1] * patch[2]
+    d = dx_b.shape[1]
+    assert dx_b.dtype == torch.bfloat16 and dx_b.shape[0] == M * B * (cls_rows + P) and dx_b.is_contiguous()
+    need = _lib.load().xvit_patch_embed_wgrad_workspace_bytes(C.byref(g), d)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=img.device)
+    dW = torch.empty(d, pd, dtype=torch.float32, device=img.device)
+    _run("gemm_big_tn+splitk", 2.0 * M * B * P * d * pd, "flop",
+         lambda: _lib.load().xvit_patch_embed_wgrad(_ptr(img), C.byref(g), _ptr(dx_b), dx_b.stride(0), _ptr(dW), dW.stride(0), d, _ptr(ws), need, _stream()),
+         "xvit_patch_embed_wgrad")
+    return dW
+
+
 def cls_row_fwd(cls, pos, x, MB, N, d):
     _lib.check(_lib.load().xvit_cls_row_fwd(_ptr(cls), _ptr(pos), _ptr(x), MB, N, d, _stream()), "xvit_cls_row_fwd")
 

@@ -178,6 +178,30 @@ int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v,
 int xvit_patchify(const void* img, int img_dtype, void* patches_bf16, int B, int M, int D, int H, int W, int dp, int hp, int wp,
                   int64_t stride_b, int64_t stride_m, int row_off, int zero_rows, int64_t zero_row_stride, xvit_stream_t stream);
 /* ------------------------------------------------------------------------------------------
+ * Patch embedding straight from the volume (model_cross.py:193-197: rearrange -> patch_to_embedding -> + pos_embedding):
+ *   x[(m*B + b)*(cls_rows + P) + cls_rows + t, :] = patch(b, m, t) W^T + bias + pos[cls_rows + t, :]
+ * with the token / feature order of xvit_patchify, WITHOUT writing the [rows, dp*hp*wp] patch matrix: the GEMM's LDS-DMA
+ * loaders gather the patch rows from img [B, M, 1, D, H, W] (bf16, contiguous).  CLS rows (cls_rows = 1) come out as
+ * bias + pos[0] and are overwritten by xvit_cls_row_fwd, exactly as with a zero CLS row in a stored patch matrix.
+ * xvit_patch_embed_wgrad: dW[d, pd] = sum over patch rows of dx[row, :]^T patch(row) (CLS rows of dx are skipped), fp32,
+ * split over the contraction into the caller's workspace and summed in a fixed order (deterministic).
+ * xvit_patch_embed_supported: 1 when the geometry fits the fused kernels (wp in {8,16,32,64}, hp*wp % 64 == 0, 64 % (D/dp) == 0,
+ * (D/dp)*(W/wp) % 64 == 0, pd and d multiples of 256, >= 2048 rows, volume < 2 GiB); otherwise use xvit_patchify + xvit_gemm.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct xvit_patch_geom {
+  int32_t B, M;          /* img [B, M, 1, D, H, W] */
+  int32_t D, H, W;
+  int32_t dp, hp, wp;    /* patch_size (model_cross.py:151) */
+  int32_t cls_rows;      /* 1: every sample's rows start with one CLS row (ModelCross); 0: patch rows only */
+} xvit_patch_geom;
+int xvit_patch_embed_supported(const xvit_patch_geom* g, int d);
+int xvit_patch_embed_fwd(const void* img_bf16, const xvit_patch_geom* g, const void* W_bf16, int64_t ldw, const float* bias, const float* pos, int64_t ldpos,
+                         float* x, int64_t ldx, int d, xvit_stream_t stream);
+int64_t xvit_patch_embed_wgrad_workspace_bytes(const xvit_patch_geom* g, int d);
+int xvit_patch_embed_wgrad(const void* img_bf16, const xvit_patch_geom* g, const void* dx_bf16, int64_t lddx, float* dW, int64_t lddw, int d, void* workspace,
+                           int64_t workspace_bytes, xvit_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Input stage (dataset_ucsf.py:84-88, 152-158): MONAI `ResizeWithPadOrCropd(spatial_size, constant_values=pad_value)`
  * followed by `.to(torch.float)`, on the raw int16 NIfTI voxels already on the device:
  * src int16 [nvol, Ds, Hs, Ws] -> dst bf16 [nvol, D, H, W].  Per dimension: symmetric pad with before = deficit/2
