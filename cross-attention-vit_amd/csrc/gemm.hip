@@ -322,13 +322,25 @@ constexpr int T_OPER = TBM * BK * 2;     // 32 KiB per operand per stage
 constexpr int T_STAGE = 2 * T_OPER;      // 64 KiB
 constexpr int T_LDS = 2 * T_STAGE;       // 128 KiB
 
+// Weight-gradient K-step: LDS k-row kr of both operands holds token gather_krow_token(kr) of the 64-token group (the
+// contraction order is free as long as dx and the volume agree).  One LDS-DMA instruction fills two k-rows; pairing the
+// tokens (w, d) and (w + 1, d) puts their 16-voxel runs side by side: 64 contiguous bytes per (p1, p2) instead of two
+// 32-byte pieces 512 KiB apart.
+__device__ __forceinline__ int gather_krow_token(const GemmParams::PatchGather& g, int kr) {
+  const int nw = 64 / g.Dn;
+  if (nw & 1) return kr;
+  const int a = kr >> 1, b = kr & 1, wa = a / g.Dn, d = a - wa * g.Dn;
+  return d + g.Dn * (2 * wa + b);
+}
+
 template <bool KS>
 struct BigLoader {
   __amdgpu_buffer_rsrc_t rsrc;
   uint32_t voff[4];
   uint32_t kstep;
   // 32 KiB image = 32 pieces of 1 KiB; wave w moves pieces 4w .. 4w+3
-  __device__ __forceinline__ void init(const bf16* tile_base, int64_t bytes_avail, int64_t ld, int wave, int lane) {
+  // perm != nullptr (weight gradient of the gathered patch embedding): LDS k-row kr is source row gather_krow_token(kr)
+  __device__ __forceinline__ void init(const bf16* tile_base, int64_t bytes_avail, int64_t ld, int wave, int lane, const GemmParams::PatchGather* perm = nullptr) {
     rsrc = make_rsrc(tile_base, clamp_bytes(bytes_avail));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -336,7 +348,8 @@ struct BigLoader {
       if (KS) {  // image [64 k][256 cols], 512-B rows: a piece is 2 k-rows
         const int krow = piece * 2 + (lane >> 5);
         const int chunk = (lane & 31) ^ swz_ks(krow);
-        voff[j] = (uint32_t)(krow * ld * 2 + chunk * 16);
+        const int srow = perm ? gather_krow_token(*perm, krow) : krow;
+        voff[j] = (uint32_t)(srow * ld * 2 + chunk * 16);
       } else {   // image [256 rows][64 k], 128-B rows: a piece is 8 rows
         const int row = piece * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ swz_kc(row);
@@ -350,7 +363,10 @@ struct BigLoader {
     rsrc = make_rsrc(vol, g.vol_bytes);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int rl = (wave * 4 + j) * 8 + (lane >> 3), row = m0 + rl;
+      // LDS row rl = 32 wave + 8 j + ii holds tile row 32 wave + (ii % 4) 8 + 2 j + ii / 4: the 8 rows of one DMA instruction are
+      // two groups of 4 tokens that are neighbours along W, so each of its 4 x 2 runs covers a whole 128-byte line (4 x 32 B)
+      // instead of 32 lines of 32 bytes; the epilogue un-permutes in its LDS transpose (wave_tile_epilogue<PERM>)
+      const int ii = lane >> 3, rl = (wave * 4 + j) * 8 + ii, row = m0 + wave * 32 + (ii & 3) * 8 + 2 * j + (ii >> 2);
       const int chunk = (lane & 7) ^ swz_kc(rl);
       const int smp = row / g.ntok, n = row - smp * g.ntok;
       voff[j] = (row < M && n >= g.cls) ? 2u * (gather_sample_origin(g, smp) + gather_patch_origin(g, n - g.cls) + gather_elem_off(g, chunk * 8)) : GATHER_OOB;
@@ -364,7 +380,8 @@ struct BigLoader {
     for (int j = 0; j < 4; ++j) {
       const int krow = (wave * 4 + j) * 2 + (lane >> 5);
       const int e = n0 + (((lane & 31) ^ swz_ks(krow)) << 3);
-      voff[j] = e < N ? 2u * ((uint32_t)((krow % g.Dn) * g.dp * g.Sz + (krow / g.Dn) * g.wp) + gather_elem_off(g, e)) : GATHER_OOB;
+      const int tok = gather_krow_token(g, krow);
+      voff[j] = e < N ? 2u * ((uint32_t)((tok % g.Dn) * g.dp * g.Sz + (tok / g.Dn) * g.wp) + gather_elem_off(g, e)) : GATHER_OOB;
     }
     kstep = 0;
   }
@@ -586,14 +603,18 @@ __device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32
 // Region R (0..7) of the wave's 128-row tile = 4 bodies = rows 16 R .. 16 R + 15; regions 0-3 and 4-7 share one LDS
 // transpose pass each (64 rows: accumulators -> LDS column-wise, read back row-wise).  `cur` holds this region's
 // pre-issued z loads (GELU' only); the next region's are issued before this region's stores.
-template <int ACT, bool DROP, int R>
+template <int ACT, bool DROP, int R, bool PERM = false>
 __device__ __forceinline__ void big_epi_regions(const GemmParams& p, BigEpi& e, LoadCursor& lc, EpiLoads& cur, const f32x4 (&acc)[8][4], XVIT_LDS char* slice,
-                                                const uint32_t (&woff)[4], const uint32_t (&roff)[4]) {
+                                                const uint32_t (&woff)[8], const uint32_t (&roff)[4]) {
   if constexpr ((R & 3) == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) *(XVIT_LDS f32x4*)(slice + i * 4096 + woff[j]) = acc[(R >> 2) * 4 + i][j];
+      for (int j = 0; j < 4; ++j) {
+        // PERM (gathered patch rows): accumulator row 16 i + r of the pass is output row 32 (i / 2) + perm32(16 (i % 2) + r)
+        if constexpr (PERM) *(XVIT_LDS f32x4*)(slice + (i >> 1) * 8192 + woff[(i & 1) * 4 + j]) = acc[(R >> 2) * 4 + i][j];
+        else *(XVIT_LDS f32x4*)(slice + i * 4096 + woff[j]) = acc[(R >> 2) * 4 + i][j];
+      }
   }
   EpiLoads nxt;
   if constexpr (ACT == XVIT_ACT_DGELU && R < 7) big_epi_issue_aux(p, e, lc, nxt);
@@ -604,16 +625,16 @@ __device__ __forceinline__ void big_epi_regions(const GemmParams& p, BigEpi& e, 
     big_epi_body<ACT, DROP>(p, e, v, cur.aux[b]);
   }
   __builtin_amdgcn_sched_barrier(0);   // one region per scheduling window
-  if constexpr (R < 7) big_epi_regions<ACT, DROP, R + 1>(p, e, lc, nxt, acc, slice, woff, roff);
+  if constexpr (R < 7) big_epi_regions<ACT, DROP, R + 1, PERM>(p, e, lc, nxt, acc, slice, woff, roff);
 }
 
-template <int ACT, bool DROP>
-__device__ __forceinline__ void big_epilogue(const GemmParams& p, BigEpi& e, const f32x4 (&acc)[8][4], XVIT_LDS char* slice, const uint32_t (&woff)[4],
+template <int ACT, bool DROP, bool PERM = false>
+__device__ __forceinline__ void big_epilogue(const GemmParams& p, BigEpi& e, const f32x4 (&acc)[8][4], XVIT_LDS char* slice, const uint32_t (&woff)[8],
                                              const uint32_t (&roff)[4]) {
   LoadCursor lc = {e.row, e.aux};
   EpiLoads first;
   if constexpr (ACT == XVIT_ACT_DGELU) big_epi_issue_aux(p, e, lc, first);
-  big_epi_regions<ACT, DROP, 0>(p, e, lc, first, acc, slice, woff, roff);
+  big_epi_regions<ACT, DROP, 0, PERM>(p, e, lc, first, acc, slice, woff, roff);
   if (p.colsum && !e.to_slab) {   // += column sums of the stored tile: lanes l, l+16, l+32, l+48 share their 4 columns
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -784,6 +805,7 @@ __device__ __forceinline__ void wave_tile_epilogue_wide(const GemmParams& p, con
 
 // Epilogue of one wave's 128 x 64 accumulator tile whose first element is (row0, col0); shared by every tile kernel
 // (the block's stage buffers are idle by now: wave w bounces through smem + w * EPI_WAVE_BYTES).
+template <bool PERM = false>
 __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, const f32x4 (&acc)[8][4], XVIT_LDS char* smem, int wave, int lane, int row0, int col0,
                                                    int batch, int split) {
   const int nbatch = gridDim.z / p.split_k;
@@ -804,11 +826,19 @@ __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, const f3
   const int wl = lane + pin;
   // LDS slice offsets: accumulator layout (row r = lane & 15 of each 16-row tile, chunk 4 J + g) and read-back
   // layout (row 4 it + rr, chunk k), both with chunk ^= row & 15
-  uint32_t woff[4], roff[4];
+  uint32_t woff[8], roff[4];
   {
     const int r = wl & 15, g = wl >> 4, k = wl & 15, rr = wl >> 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) woff[j] = (uint32_t)(r * 256 + (((j * 4 + g) ^ r) << 4));
+    for (int j = 0; j < 4; ++j) woff[j] = woff[4 + j] = (uint32_t)(r * 256 + (((j * 4 + g) ^ r) << 4));
+    if constexpr (PERM) {   // LDS row 8 jj + ii of a 32-row group holds tile row (ii % 4) 8 + 2 jj + ii / 4 (BigLoader::init_gather_rows)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int l32 = 16 * half + r, jj = l32 >> 3, ii = l32 & 7, rho = (ii & 3) * 8 + 2 * jj + (ii >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) woff[half * 4 + j] = (uint32_t)(rho * 256 + (((j * 4 + g) ^ (rho & 15)) << 4));
+      }
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) roff[q] = (uint32_t)(rr * 256 + ((k ^ (q * 4 + rr)) << 4));
   }
@@ -841,6 +871,10 @@ __device__ __forceinline__ void wave_tile_epilogue(const GemmParams& p, const f3
     e.res_wrap = rmap ? e.rmod * (uint32_t)p.ldr * 4u : 0u;
   }
   // one specialised, fully unrolled copy per (activation, dropout): every acc[][] index is a compile-time constant
+  if constexpr (PERM) {   // the patch-embedding forward: bias + positional residual only
+    big_epilogue<XVIT_ACT_NONE, false, true>(p, e, acc, slice, woff, roff);
+    return;
+  }
   if (p.drop_p > 0.f) {
     if (p.act == XVIT_ACT_GELU) big_epilogue<XVIT_ACT_GELU, true>(p, e, acc, slice, woff, roff);
     else if (p.act == XVIT_ACT_DGELU) big_epilogue<XVIT_ACT_DGELU, true>(p, e, acc, slice, woff, roff);
@@ -905,7 +939,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
     if constexpr (GATHER == 1) la.init_gather_rows(p.g, Ab, m0, p.M, wave, lane);
     else if constexpr (GATHER == 2) {   // dY rows are re-indexed per K-step (CLS rows skipped): base = row 0, K-step offsets from gather_soff_wgrad
       const int64_t rows = (int64_t)(p.K / p.g.pcount) * p.g.ntok;
-      la.init(Ab + m0, ((rows - 1) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane);
+      la.init(Ab + m0, ((rows - 1) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane, &p.g);
     } else if (A_KS) la.init(Ab + (int64_t)k_begin * p.lda + m0, ((int64_t)(k_end - 1 - k_begin) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane);
     else la.init(Ab + (int64_t)m0 * p.lda + k_begin, ((int64_t)(p.M - 1 - m0) * p.lda + (k_end - k_begin)) * 2, p.lda, wave, lane);
     const bf16* Bb = p.B + batch * p.sB;
@@ -955,7 +989,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last iteration's (zero-fill) DMAs have landed before the stage buffers are recycled
   __syncthreads();   // every wave is done reading the last stage: the stage buffers become the transpose slices
   if constexpr (WIDE_ACT >= 0) wave_tile_epilogue_wide<WIDE_ACT>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, batch);
-  else wave_tile_epilogue(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, batch, split);
+  else wave_tile_epilogue<GATHER == 1>(p, acc, smem, wave, lane, m0 + wr * 128, n0 + wc * 64, batch, split);
 }
 
 // split-K second pass: sum the partial tiles in a fixed order (bit-reproducible), then the full epilogue
