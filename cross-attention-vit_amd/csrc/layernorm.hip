@@ -12,15 +12,15 @@ constexpr int LNB_WAVES = 4;   // backward: 4-wave blocks, [4][2][d] LDS reducti
 
 template <int V>  // V float4 per lane: d <= 256*V
 __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ x_alt, int64_t ldx,
-                                                               int seq_len, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               int seq_len, int64_t ld_alt, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float eps, bf16* __restrict__ y, int64_t ldy, float* __restrict__ yf, int64_t ldyf,
                                                                float* __restrict__ mean, float* __restrict__ rstd, int rows, int d) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = d >> 2;  // float4 per row
   const float inv_d = 1.0f / (float)d;
   for (int row = blockIdx.x * LN_WAVES + wave; row < rows; row += gridDim.x * LN_WAVES) {
-    const float* src = (x_alt && (row % seq_len) == 0) ? x_alt : x;
-    const f32x4* xr = (const f32x4*)(src + (int64_t)row * ldx);
+    // row 0 of every sequence may come from x_alt (the CLS rows of the other operand, one every ld_alt elements)
+    const f32x4* xr = (const f32x4*)((x_alt && (row % seq_len) == 0) ? x_alt + (int64_t)(row / seq_len) * ld_alt : x + (int64_t)row * ldx);
     f32x4 v[V];
     float s = 0.f;
 #pragma unroll
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const float* __re
 
 template <int V>
 __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const bf16* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
-                                                               const float* __restrict__ x_alt, int64_t ldx, int seq_len,
+                                                               const float* __restrict__ x_alt, int64_t ldx, int seq_len, int64_t ld_alt,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ dres, int64_t lddres,
                                                                float* __restrict__ dx, int64_t lddx, bf16* __restrict__ dxb, int64_t lddxb,
@@ -83,8 +83,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const bf16* __re
     sr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
-    const float* src = (x_alt && (row % seq_len) == 0) ? x_alt : x;
-    const f32x4* xr = (const f32x4*)(src + (int64_t)row * ldx);
+    const f32x4* xr = (const f32x4*)((x_alt && (row % seq_len) == 0) ? x_alt + (int64_t)(row / seq_len) * ld_alt : x + (int64_t)row * ldx);
     const bf16* dyr = dy + (int64_t)row * lddy;
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[V], gy[V];
@@ -192,24 +191,24 @@ static int ln_grid(int rows) {
   return want < 2048 ? want : 2048;  // grid-stride beyond 8 blocks/CU
 }
 
-extern "C" int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_len, const float* gamma, const float* beta,
+extern "C" int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_len, int64_t ld_alt, const float* gamma, const float* beta,
                                   float eps, void* y, int64_t ldy, float* y_f32, int64_t ldyf, float* mean, float* rstd, int rows, int d,
                                   xvit_stream_t stream) {
   XVIT_REQUIRE(x && gamma && beta && (y || y_f32) && mean && rstd, "xvit_layernorm_fwd: null pointer");
   XVIT_REQUIRE(!y_f32 || (ldyf % 4 == 0 && ldyf >= d), "xvit_layernorm_fwd: ldyf must be a multiple of 4 and >= d");
   XVIT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 4096, "xvit_layernorm_fwd: need 0 < d <= 4096, d %% 4 == 0 (d=%d rows=%d)", d, rows);
   XVIT_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= d && ldy >= d, "xvit_layernorm_fwd: ldx/ldy must be multiples of 4 and >= d");
-  XVIT_REQUIRE(!x_alt || seq_len > 0, "xvit_layernorm_fwd: x_alt needs seq_len > 0");
+  XVIT_REQUIRE(!x_alt || (seq_len > 0 && ld_alt >= d && ld_alt % 4 == 0), "xvit_layernorm_fwd: x_alt needs seq_len > 0 and ld_alt >= d, a multiple of 4");
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(ln_grid(rows)), block(LN_WAVES * 64);
   bf16* yb = (bf16*)y;
-  if (d <= 768) hipLaunchKernelGGL((ln_fwd_kernel<3>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, y_f32, ldyf, mean, rstd, rows, d);
-  else if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, y_f32, ldyf, mean, rstd, rows, d);
-  else hipLaunchKernelGGL((ln_fwd_kernel<16>), grid, block, 0, s, x, x_alt, ldx, seq_len, gamma, beta, eps, yb, ldy, y_f32, ldyf, mean, rstd, rows, d);
+  if (d <= 768) hipLaunchKernelGGL((ln_fwd_kernel<3>), grid, block, 0, s, x, x_alt, ldx, seq_len, ld_alt, gamma, beta, eps, yb, ldy, y_f32, ldyf, mean, rstd, rows, d);
+  else if (d <= 1024) hipLaunchKernelGGL((ln_fwd_kernel<4>), grid, block, 0, s, x, x_alt, ldx, seq_len, ld_alt, gamma, beta, eps, yb, ldy, y_f32, ldyf, mean, rstd, rows, d);
+  else hipLaunchKernelGGL((ln_fwd_kernel<16>), grid, block, 0, s, x, x_alt, ldx, seq_len, ld_alt, gamma, beta, eps, yb, ldy, y_f32, ldyf, mean, rstd, rows, d);
   return check_launch("xvit_layernorm_fwd");
 }
 
-extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len,
+extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len, int64_t ld_alt,
                                   const float* mean, const float* rstd, const float* gamma, const float* dres, int64_t lddres, float* dx,
                                   int64_t lddx, void* dxb, int64_t lddxb, float* dgamma, float* dbeta, float* dxsum, float* dressum, int rows,
                                   int d, float* workspace, int64_t workspace_bytes, xvit_stream_t stream) {
@@ -217,7 +216,7 @@ extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, 
   XVIT_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 4096, "xvit_layernorm_bwd: need 0 < d <= 4096, d %% 4 == 0 (d=%d rows=%d)", d, rows);
   XVIT_REQUIRE(ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && (!dres || lddres % 4 == 0) && (!dxb || lddxb % 4 == 0),
                "xvit_layernorm_bwd: leading dimensions must be multiples of 4");
-  XVIT_REQUIRE(!x_alt || seq_len > 0, "xvit_layernorm_bwd: x_alt needs seq_len > 0");
+  XVIT_REQUIRE(!x_alt || (seq_len > 0 && ld_alt >= d && ld_alt % 4 == 0), "xvit_layernorm_bwd: x_alt needs seq_len > 0 and ld_alt >= d, a multiple of 4");
   XVIT_REQUIRE(!dressum || dres, "xvit_layernorm_bwd: dressum needs dres");
   hipStream_t s = (hipStream_t)stream;
   int g = (rows + LNB_WAVES - 1) / LNB_WAVES;
@@ -229,11 +228,11 @@ extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, 
   const bf16* dyb = (const bf16*)dy;
   bf16* dxbb = (bf16*)dxb;
   if (d <= 768)
-    hipLaunchKernelGGL((ln_bwd_kernel<3>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, workspace, rows, d);
+    hipLaunchKernelGGL((ln_bwd_kernel<3>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, ld_alt, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, workspace, rows, d);
   else if (d <= 1024)
-    hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, workspace, rows, d);
+    hipLaunchKernelGGL((ln_bwd_kernel<4>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, ld_alt, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, workspace, rows, d);
   else
-    hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, workspace, rows, d);
+    hipLaunchKernelGGL((ln_bwd_kernel<16>), grid, block, lds, s, dyb, lddy, x, x_alt, ldx, seq_len, ld_alt, mean, rstd, gamma, dres, lddres, dx, lddx, dxbb, lddxb, dgamma, dbeta, dxsum, dressum, workspace, rows, d);
   if (workspace) {
     // without dxsum / dressum the kernel skips round 1: those slices of the workspace are never read either
     hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 255) / 256), dim3(256), 0, s, workspace, dgamma, dbeta, dxsum, dressum, g, d);

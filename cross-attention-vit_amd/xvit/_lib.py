@@ -33,9 +33,9 @@ SIGNATURES = {
     "xvit_gemm": [C.POINTER(GemmArgs), vp],
     "xvit_small_linear_fwd": [vp, i64, vp, vp, vp, i32, i32, i32, vp],
     "xvit_small_linear_bwd": [vp, vp, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp],
-    "xvit_layernorm_fwd": [vp, vp, i64, i32, vp, vp, f32, vp, i64, vp, i64, vp, vp, i32, i32, vp],
+    "xvit_layernorm_fwd": [vp, vp, i64, i32, i64, vp, vp, f32, vp, i64, vp, i64, vp, vp, i32, i32, vp],
     "xvit_linear_f32": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, f32, u64, vp, i64, vp],
-    "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, i64, vp],
+    "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, i64, vp],
     "xvit_attn_fwd": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_cls_xattn_fwd": [vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],

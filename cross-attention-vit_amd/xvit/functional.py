@@ -389,7 +389,7 @@ class EncoderBlockFn(Function):
 # ------------------------------------------------------------------------------------------
 
 
-def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq, bq, wkv_s, bkv, wp, bp, ln2w, ln2b, w1, b1, w2, b2, p=0.0, seeds=(0, 0, 0, 0)):
+def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq, bq, wkv_s, bkv, wp, bp, ln2w, ln2b, w1, b1, w2, b2, p=0.0, seeds=(0, 0, 0, 0), pack_cls=False):
     """xi, xj fp32 [B*N, d] (cls taken from xi, patch tokens from xj) -> (y2 fp32 [B, d], saved).
 
     Two precisions on purpose.  The key/value projection runs over all N tokens: bf16 operands on the MFMA tile kernels
@@ -411,12 +411,14 @@ def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq, bq, wkv_s, bkv, wp, bp, 
     h2f, h2, mu2, rs2 = ops.layernorm_fwd_f32(y, ln2w, ln2b, eps)
     af, a, z = ops.linear_f32(h2f, w1, b1, act=ops.ACT_GELU, want_z=True, want_bf16=True, dropout=_dp(p, seeds[2]))
     y2, _, _ = ops.linear_f32(af, w2, b2, residual=y, dropout=_dp(p, seeds[3]))
-    return y2, (xi, xj, mu, rs, hn, kv, qb, oc, pr, y, mu2, rs2, h2, z, a)
+    # the backward needs xi only for its CLS rows (row 0 of the normed concat): a packed [B, d] copy when the caller is about
+    # to overwrite them in place (CrossFusionFn), else xi itself
+    return y2, (cls_in.clone() if pack_cls else xi, xj, mu, rs, hn, kv, qb, oc, pr, y, mu2, rs2, h2, z, a)
 
 
 def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, pd=0.0, seeds=(0, 0, 0, 0)):
     """dy2 fp32 [B, d] -> (dcat fp32 [B*N, d] = grad of the normed concat input, dcls_res fp32 [B, d], grads)."""
-    xi, xj, mu, rs, hn, kv, q, oc, p, y, mu2, rs2, h2, z, a = saved
+    xi, xj, mu, rs, hn, kv, q, oc, p, y, mu2, rs2, h2, z, a = saved       # xi: the token tensor or a packed copy of its CLS rows
     d, f = xi.shape[1], z.shape[1]
     scale = (d // H) ** -0.5
     zero = torch.zeros(6 * d + f, dtype=torch.float32, device=xi.device)
@@ -462,20 +464,29 @@ class CrossFusionFn(Function):
         bkv = torch.cat((bk, bv)).detach()
         xi2, xj2 = _f32c(xi).reshape(B * N, d), _f32c(xj).reshape(B * N, d)
         seeds = drop_seeds(4) if p > 0.0 else (0, 0, 0, 0)
+        # concat: the output is x_i with its CLS rows replaced by the fused token (model_cross.py:142).  x_i has no other
+        # reader of those rows (the other fusions take its PATCH rows, the producing block saves its input, not its output), so
+        # the new rows are written IN PLACE and the block's output aliases x_i: no 166 MB copy per fusion.  The write goes
+        # through .data (no version bump: autograd must not take x_i's patch rows, saved by the other fusion, for modified)
+        # and the backward keeps a packed copy of the original CLS rows.  XVIT_CLS_INPLACE=0 restores the copying form.
+        inplace = concat and os.environ.get("XVIT_CLS_INPLACE", "1") == "1"
         y2, saved = cross_forward(xi2, xj2, B, N, H, eps, ln1w, ln1b, wq.detach(), bq, sh[1], bkv, wp.detach(), bp, ln2w, ln2b, w1.detach(), b1,
-                                  w2.detach(), b2, p, seeds)
+                                  w2.detach(), b2, p, seeds, pack_cls=inplace)
         ctx.drop = (p, seeds)
-        ctx.meta = (B, N, H, d, concat)
+        ctx.meta = (B, N, H, d, concat, inplace)
         ctx.save_for_backward(ln1w, ln2w, *sh, *saved)
         if not concat:
             return y2.reshape(B, 1, d)
+        if inplace:
+            xi2.data.reshape(B, N * d)[:, :d].copy_(y2)
+            return xi2.reshape(B, N, d)
         out = xi2.clone().reshape(B, N, d)
         out[:, 0] = y2
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        B, N, H, d, concat = ctx.meta
+        B, N, H, d, concat, inplace = ctx.meta
         ln1w, ln2w, wq_s, wkv_s, wp_s, w1_s, w2_s, *saved = ctx.saved_tensors
         dout = _f32c(dout)
         dy2 = dout[:, 0].contiguous()
@@ -483,7 +494,9 @@ class CrossFusionFn(Function):
         dcat = dcat.reshape(B, N, d)
         # cls row -> x_i (normed-concat path + the un-normed residual path); patch rows -> x_j
         if concat:
-            dxi = dout.clone()
+            # in-place form: the incoming gradient has this node as its only consumer (the block's output feeds one branch),
+            # so its CLS rows are replaced where they are
+            dxi = dout if inplace else dout.clone()
         else:
             dxi = torch.zeros(B, N, d, dtype=torch.float32, device=dout.device)
         dxi[:, 0] = dcat[:, 0] + dcls_res

@@ -151,16 +151,27 @@ def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NON
     return C_out
 
 
+def _alt_ld(x, x_alt, seq_len):
+    """Row stride between the x_alt rows of consecutive sequences: x_alt is either a tensor laid out like x (its rows
+    k * seq_len are used) or a packed [sequences, d] copy of those rows."""
+    if x_alt is None:
+        return 0
+    rows, d = x.shape
+    if x_alt.shape == x.shape and x_alt.stride() == x.stride():
+        return seq_len * _rows2d(x)
+    assert seq_len > 0 and x_alt.shape == (rows // seq_len, d) and x_alt.stride(1) == 1 and x_alt.dtype == torch.float32
+    return x_alt.stride(0)
+
+
 def layernorm_fwd(x, gamma, beta, eps, *, x_alt=None, seq_len=0, out=None):
     """x fp32 [rows, d] (row stride free) -> (y bf16 [rows, d], mean, rstd)."""
     rows, d = x.shape
     y = out if out is not None else torch.empty(rows, d, dtype=torch.bfloat16, device=x.device)
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    if x_alt is not None:
-        assert x_alt.shape == x.shape and x_alt.stride() == x.stride()
+    ld_alt = _alt_ld(x, x_alt, seq_len)
     _run("layernorm_fwd", rows * d * 6.0, "byte",
-         lambda: _lib.load().xvit_layernorm_fwd(_ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(gamma), _ptr(beta), eps,
+         lambda: _lib.load().xvit_layernorm_fwd(_ptr(x), _ptr(x_alt), _rows2d(x), seq_len, ld_alt, _ptr(gamma), _ptr(beta), eps,
                                                 _ptr(y), _rows2d(y), None, 0, _ptr(mean), _ptr(rstd), rows, d, _stream()), "xvit_layernorm_fwd")
     return y, mean, rstd
 
@@ -172,7 +183,7 @@ def layernorm_fwd_f32(x, gamma, beta, eps, want_bf16=True):
     yb = torch.empty(rows, d, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     mean = torch.empty(rows, dtype=torch.float32, device=x.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().xvit_layernorm_fwd(_ptr(x), None, _rows2d(x), 0, _ptr(gamma), _ptr(beta), eps, _ptr(yb), d, _ptr(yf), d,
+    _lib.check(_lib.load().xvit_layernorm_fwd(_ptr(x), None, _rows2d(x), 0, 0, _ptr(gamma), _ptr(beta), eps, _ptr(yb), d, _ptr(yf), d,
                                               _ptr(mean), _ptr(rstd), rows, d, _stream()), "xvit_layernorm_fwd")
     return yf, yb, mean, rstd
 
@@ -208,8 +219,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, *, x_alt=None, seq_le
     if DETERMINISTIC:
         ws_bytes = _lib.load().xvit_layernorm_bwd_workspace_bytes(rows, d)
         ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    ld_alt = _alt_ld(x, x_alt, seq_len)
     _run("layernorm_bwd", nbytes, "byte", lambda: _lib.load().xvit_layernorm_bwd(
-        _ptr(dy), _rows2d(dy), _ptr(x), _ptr(x_alt), _rows2d(x), seq_len, _ptr(mean), _ptr(rstd), _ptr(gamma),
+        _ptr(dy), _rows2d(dy), _ptr(x), _ptr(x_alt), _rows2d(x), seq_len, ld_alt, _ptr(mean), _ptr(rstd), _ptr(gamma),
         _ptr(dres), _rows2d(dres) if dres is not None else 0, _ptr(dx), d, _ptr(dxb), d,
         _ptr(dgamma), _ptr(dbeta), _ptr(dxsum), _ptr(dressum), rows, d, _ptr(ws), ws_bytes, _stream()), "xvit_layernorm_bwd")
     return dx, dxb

@@ -113,20 +113,21 @@ int xvit_small_linear_bwd(const float* dy, const void* x_bf16, int64_t ldx, cons
 
 /* ------------------------------------------------------------------------------------------
  * LayerNorm (model_cross.py:11-17 PreNorm, :174/:203 final norm; model.py:186-187,207 eps=1e-6).
- * x is the fp32 residual stream [rows, d] (row stride ldx).  If x_alt != NULL, rows with
- * (row % seq_len) == 0 are read from x_alt at the same offset: the "cls of i + patches of j"
- * concatenation of model_cross.py:140 without materialising it.
+ * x is the fp32 residual stream [rows, d] (row stride ldx).  If x_alt != NULL, row k * seq_len (the first row of
+ * sequence k) is read from x_alt + k * ld_alt instead: the "cls of i + patches of j" concatenation of model_cross.py:140
+ * without materialising it (ld_alt = seq_len * ldx when x_alt is the other modality's token tensor, = d for a packed
+ * [sequences, d] copy of its CLS rows).
  * Outputs: y_bf16 (the GEMM operand) and / or y_f32 (the fp32 copy the single-token CLS path feeds to xvit_linear_f32);
  * either may be NULL, not both.
  * ---------------------------------------------------------------------------------------- */
-int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_len, const float* gamma, const float* beta,
+int xvit_layernorm_fwd(const float* x, const float* x_alt, int64_t ldx, int seq_len, int64_t ld_alt, const float* gamma, const float* beta,
                        float eps, void* y_bf16, int64_t ldy, float* y_f32, int64_t ldyf, float* mean, float* rstd, int rows, int d,
                        xvit_stream_t stream);
 /* dx = (dres ? dres : 0) + LN'(dy); also emits a bf16 copy of dx (the next GEMMs' operand) when
  * dx_bf16 != NULL; dgamma/dbeta are ADDED (fp32 atomics).  Optional dxsum[d] += column sums of dx and
  * dressum[d] += column sums of dres: the bias gradients of the Linears on either side of the norm
  * (dx is the dy of the Linear that produced x; dres the dy of the Linear whose output joined x), for free. */
-int xvit_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len,
+int xvit_layernorm_bwd(const void* dy_bf16, int64_t lddy, const float* x, const float* x_alt, int64_t ldx, int seq_len, int64_t ld_alt,
                        const float* mean, const float* rstd, const float* gamma, const float* dres, int64_t lddres,
                        float* dx, int64_t lddx, void* dx_bf16, int64_t lddxb, float* dgamma, float* dbeta, float* dxsum,
                        float* dressum, int rows, int d, float* workspace, int64_t workspace_bytes, xvit_stream_t stream);

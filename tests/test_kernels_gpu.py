@@ -50,6 +50,17 @@ def test_layernorm_row0_from_other_tensor():
     y, _, _ = ops.layernorm_fwd(xj.to(dev()).reshape(B * N, d), g.to(dev()), b.to(dev()), 1e-5, x_alt=xi.to(dev()).reshape(B * N, d), seq_len=N)
     cat = torch.cat((xi[:, 0:1], xj[:, 1:]), dim=1)
     assert_close(y.reshape(B, N, d), R.layer_norm(cat, g, b), "ln with x_alt")
+    # the same rows from a packed [B, d] copy of the CLS rows (the in-place CLS splice keeps only that copy)
+    packed = xi[:, 0].contiguous().to(dev())
+    y2, mean2, rstd2 = ops.layernorm_fwd(xj.to(dev()).reshape(B * N, d), g.to(dev()), b.to(dev()), 1e-5, x_alt=packed, seq_len=N)
+    assert torch.equal(y2, y)
+    dy = randn(B * N, d, seed=9).to(dev(), torch.bfloat16)
+    outs = []
+    for alt in (xi.to(dev()).reshape(B * N, d), packed):
+        dg, db = torch.zeros(d, device=dev()), torch.zeros(d, device=dev())
+        dx, _ = ops.layernorm_bwd(dy, xj.to(dev()).reshape(B * N, d), mean2, rstd2, g.to(dev()), dg, db, x_alt=alt, seq_len=N)
+        outs.append(dx)
+    assert torch.equal(outs[0], outs[1])
 
 
 # ------------------------------------------------------------------------------------ attention

@@ -397,3 +397,34 @@ def test_checkpoint_round_trip_in_lightning_layout(tmp_path):
     for m in (fresh, live):
         logits, loss = m(img, labels)
         assert torch.equal(logits, ref_logits) and float(loss.detach()) == float(ref_loss.detach())
+
+
+def test_inplace_cls_splice_equals_copying_form(monkeypatch):
+    """CrossFusionFn writes the fused CLS rows into x_i in place (no copy of the token tensor, reference model_cross.py:142
+    torch.cat): logits and EVERY gradient must equal the copying form bit for bit (XVIT_CLS_INPLACE=0), also when the
+    backward runs twice on a retained graph."""
+    import xvit
+    cfg = R.make_config("small")
+    sd = R.make_state_dict(cfg, seed=3)
+    img, labels = R.make_inputs(cfg, 3, seed=3)
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("XVIT_CLS_INPLACE", mode)
+        xvit.ops.set_deterministic(True)
+        try:
+            model = xvit.ModelCross(cfg).to(dev())
+            model.load_state_dict(sd)
+            model.train()
+            logits, loss = model(img.to(dev()), labels.to(dev()))
+            loss.backward(retain_graph=True)
+            g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+            model.zero_grad()
+            loss.backward()
+            g2 = {k: p.grad.clone() for k, p in model.named_parameters()}
+        finally:
+            xvit.ops.set_deterministic(False)
+        assert all(torch.equal(g1[k], g2[k]) for k in g1), "second backward over the retained graph differs"
+        res[mode] = (logits.detach().clone(), g1)
+    assert torch.equal(res["1"][0], res["0"][0])
+    for k in res["1"][1]:
+        assert torch.equal(res["1"][1][k], res["0"][1][k]), k
