@@ -282,13 +282,23 @@ def _f32c(t):
 # ------------------------------------------------------------------------------------------
 
 
+def _attn_fwd(qkv, B, N, H, scale, p=0.0, seed=0):
+    """Forward attention of the all-token blocks.  XVIT_ATTN_FP8=1 (opt-in, SURVEY.md 8 / configs[4]) runs QK^T and P.V on the
+    MX-fp8 matrix instruction where the kernel applies (d_h = 64, no probability dropout): ~5e-2 output error instead of 2e-3
+    (tests/test_attn_fp8_gpu.py), 7 % less forward-attention time at N = 4097 and MORE time at N = 513.
+    The backward always runs the bf16 kernels on the saved o / lse."""
+    if p == 0.0 and os.environ.get("XVIT_ATTN_FP8", "0") == "1" and qkv.shape[1] // (3 * H) == 64:
+        return ops.attn_fwd_fp8(qkv, B, N, H, scale)
+    return ops.attn_fwd(qkv, B, N, H, scale, dropout=(p, seed))
+
+
 def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln2w, ln2b, w1_s, b1, w2_s, b2, p_out=0.0, p_ffn=0.0, seeds=(0, 0, 0), p_attn=0.0, seed_attn=0):
     """x fp32 [B*N, d] -> (x2 fp32 [B*N, d], saved activations).  Dropout sites (reference
     model_cross.py:47,25,27 / model.py:177,114,116): after the out-projection (p_out), after GELU and
     after the second FFN Linear (p_ffn) — all fused into the producing GEMM's epilogue."""
     h1, mu1, rs1 = ops.layernorm_fwd(x, ln1w, ln1b, eps)
     qkv = _linear(h1, wqkv_s, bias=bqkv)
-    o, lse = ops.attn_fwd(qkv, B, N, H, scale, dropout=(p_attn, seed_attn))       # model.py:169: dropout on the probabilities
+    o, lse = _attn_fwd(qkv, B, N, H, scale, p_attn, seed_attn)       # model.py:169: dropout on the probabilities
     x1 = _linear(o, wo_s, bias=bo, residual=x, out_dtype=torch.float32, dropout=_dp(p_out, seeds[0]))
     h2, mu2, rs2 = ops.layernorm_fwd(x1, ln2w, ln2b, eps)
     z = torch.empty(x.shape[0], w1_s.shape[0], dtype=torch.bfloat16, device=x.device)
@@ -742,7 +752,7 @@ class AttentionCoreFn(Function):
         B, N, d3 = qkv.shape
         q2 = _as_bf16_2d(qkv)
         seed = drop_seeds(1)[0] if p > 0.0 else 0
-        o, lse = ops.attn_fwd(q2, B, N, H, scale, dropout=(p, seed))
+        o, lse = _attn_fwd(q2, B, N, H, scale, p, seed)
         ctx.save_for_backward(q2, o, lse)
         ctx.meta = (B, N, H, scale, qkv.dtype, p, seed)
         return o.reshape(B, N, d3 // 3)

@@ -243,6 +243,22 @@ def attn_fwd(qkv, B, N, H, scale, dropout=(0.0, 0)):
     return o, lse
 
 
+def attn_fwd_fp8(qkv, B, N, H, scale):
+    """MX-fp8 forward attention (xvit_attn_fwd_fp8): qkv bf16 [B*N, 3d] -> (o bf16 [B*N, d], lse fp32 [B, H, N]); opt-in."""
+    d = qkv.shape[1] // 3
+    dh = d // H
+    o = torch.empty(B * N, d, dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
+    ld = _rows2d(qkv)
+    need = _lib.load().xvit_attn_fp8_workspace_bytes(B, H, N, dh)
+    ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+    p = _ptr(qkv)
+    _run("attn_fwd_fp8", 4.0 * B * H * N * N * dh, "flop",
+         lambda: _lib.load().xvit_attn_fwd_fp8(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), N * d, d, _ptr(lse), B, H, N, dh, scale, _ptr(ws), need, _stream()),
+         "xvit_attn_fwd_fp8")
+    return o, lse
+
+
 def attn_bwd(qkv, o, d_o, lse, B, N, H, scale, dropout=(0.0, 0)):
     """-> dqkv bf16 [B*N, 3d]."""
     d = qkv.shape[1] // 3

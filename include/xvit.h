@@ -167,6 +167,15 @@ int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v,
                        const void* d_o, int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, int B, int H, int N, int dh,
                        float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
 
+/* MX-fp8 forward attention (BASELINE.json configs[4] "fp8 MFMA QK^T/AV path"; reference ops model_cross.py:55-59):
+ * same arguments and outputs as xvit_attn_fwd without dropout, but q, k, v are first quantised to OCP e4m3 with one e8m0
+ * scale per 32 contraction elements (q, k along d_h; v transposed, along the keys) into the caller's workspace, and both
+ * products run on v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 MFMA rate).  Accuracy is that of 3-bit mantissas (stated in
+ * tests/test_attn_fp8_gpu.py); lse / o feed the bf16 backward unchanged.  Opt-in: nothing selects it by default. */
+int64_t xvit_attn_fp8_workspace_bytes(int B, int H, int N, int dh);
+int xvit_attn_fwd_fp8(const void* q, const void* k, const void* v, int64_t stride_b, int64_t stride_n, void* o, int64_t o_stride_b, int64_t o_stride_n,
+                      float* lse, int B, int H, int N, int dh, float scale, void* workspace, int64_t workspace_bytes, xvit_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * 3-D patchify (model_cross.py:193, modelv3.py:129): img [B, M, 1, D, H, W] (fp32 or bf16, contiguous) ->
  * rows of a bf16 patch matrix [*, pd]; token t = (h*Wn + w)*Dn + d, feature f = (p1*hp + p2)*wp + p3.

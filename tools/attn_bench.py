@@ -18,7 +18,8 @@ def main():
         qkv = torch.randn(B * N, 3 * d, device=dev).bfloat16()
         do = torch.randn(B * N, d, device=dev).bfloat16()
         o, lse = ops.attn_fwd(qkv, B, N, H, 0.125)
-        for name, fn, fl in (("fwd", lambda: ops.attn_fwd(qkv, B, N, H, 0.125), 4.0), ("bwd", lambda: ops.attn_bwd(qkv, o, do, lse, B, N, H, 0.125), 10.0)):
+        for name, fn, fl in (("fwd", lambda: ops.attn_fwd(qkv, B, N, H, 0.125), 4.0), ("fwd fp8 (quantise + attention)", lambda: ops.attn_fwd_fp8(qkv, B, N, H, 0.125), 4.0),
+                             ("bwd", lambda: ops.attn_bwd(qkv, o, do, lse, B, N, H, 0.125), 10.0)):
             for _ in range(3):
                 fn()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -29,7 +30,7 @@ def main():
             torch.cuda.synchronize()
             us = s.elapsed_time(e) / 20 * 1e3
             flops = fl * B * H * N * N * 64
-            print(f"attn {name} B={B:3d} N={N:5d}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s algorithmic ({flops / us / 1e6 / 25.16:5.1f} % of MFMA peak)", flush=True)
+            print(f"attn {name:32s} B={B:3d} N={N:5d}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s algorithmic ({flops / us / 1e6 / 25.16:5.1f} % of MFMA peak)", flush=True)
 
 
 if __name__ == "__main__":
