@@ -400,39 +400,14 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
 }
 
 // ------------------------------------------------------------------------------------------
-// delta[b,h,n] = sum_d dO * O
-// ------------------------------------------------------------------------------------------
-__global__ void attn_delta_kernel(const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb, int64_t osn, const float* __restrict__ lse,
-                                  float* __restrict__ delta, float* __restrict__ nlse, int H, int N, int total) {
-  // 8 lanes per (b, h, n) row: each 16 B of O and dO
-  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int rowid = gid >> 3, part = gid & 7;
-  float acc = 0.f;
-  if (rowid < total) {
-    const int n = rowid % N, bh = rowid / N, head = bh % H, b = bh / H;
-    const int64_t off = (int64_t)b * osb + (int64_t)n * osn + head * DH + part * 8;
-    const bf16x8 a = *(const bf16x8*)(o + off), g = *(const bf16x8*)(d_o + off);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc += bf2f(a[e]) * bf2f(g[e]);
-  }
-  acc += __shfl_xor(acc, 1);
-  acc += __shfl_xor(acc, 2);
-  acc += __shfl_xor(acc, 4);
-  if (rowid < total && part == 0) {
-    delta[rowid] = acc;
-    nlse[rowid] = -lse[rowid] * LOG2E;   // the backward kernels compute P = exp2(s*c + nlse): ready for LDS-DMA, no per-tile transform
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // backward, dQ: one wave = 32 queries, streams K and V tiles
 // ------------------------------------------------------------------------------------------
 // (133 VGPRs: three blocks per CU; squeezing it to 128 for a fourth spills and measured 6 % slower)
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
-                                                             int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
-                                                             const float* __restrict__ nlse_ws, const float* __restrict__ delta,
-                                                             bf16* __restrict__ dq, int H, int N, float scale, const DropArgs drop) {
+                                                             int64_t sb, int64_t sn, const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb,
+                                                             int64_t osn, const float* __restrict__ lse, float* __restrict__ nlse_ws,
+                                                             float* __restrict__ delta, bf16* __restrict__ dq, int H, int N, float scale, const DropArgs drop) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
@@ -465,9 +440,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   const bool wave_active = q0 < N;   // wave-uniform
   const int64_t stat = ((int64_t)b * H + head) * N + qrow;
   const float c = scale * LOG2E;
-  // invalid query rows: nlse = -big -> P = 0, so nothing is accumulated for them
-  float nlse = valid ? nlse_ws[stat] : -1e30f;
-  float dlt = valid ? delta[stat] : 0.f;
+  // Row statistics of the backward, computed HERE from the query rows this wave already holds (dO in registers, O loaded the
+  // same way) and left in the workspace for the dK/dV kernel, which is launched after this one: delta = rowsum(dO . O) and
+  // nlse = -lse log2(e) (P = exp2(s c + nlse): no per-tile transform).  A separate pass over O and dO (198 MB at configs[1])
+  // did this before.  Invalid query rows: nlse = -big -> P = 0, nothing is accumulated for them.
+  float nlse, dlt;
+  {
+    bf16x8 of[4];
+    load_lane_operand(of, o + (int64_t)b * osb + head * DH, osn, q0, N, lane);
+    float part = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part = fmaf(bf2f(of[ks][j]), bf2f(dof[ks][j]), part);
+    dlt = valid ? half_sum(part) : 0.f;          // the two lane halves hold the two halves of d
+    nlse = valid ? -lse[stat] * LOG2E : -1e30f;
+    if (valid && (lane >> 5) == 0) { delta[stat] = dlt; nlse_ws[stat] = nlse; }
+  }
   asm volatile("" : "+v"(nlse), "+v"(dlt));   // settle these loads (and qf/dof below) before the tile loop: see settle()
 
   f32x16 dqacc[2];
@@ -709,19 +698,19 @@ extern "C" int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_
   (void)lds_opt_in;
   const int total = B * H * N;
   float* nlse = delta + total;   // workspace = [2][B,H,N]: delta | -lse*log2e
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((total * 8 + 255) / 256), dim3(256), 0, s, (const bf16*)o, (const bf16*)d_o, osb, osn, lse, delta, nlse, H, N, total);
   const dim3 grid((N + 127) / 128, H, B), block(256);
   const DropArgs da = drop_args(dropout_p, dropout_seed);
   if (dropout_p > 0.f) {
+    // the dQ kernel first: it also leaves delta and -lse log2(e) of every query row in the workspace for the dK/dV kernel
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)o,
+                       (const bf16*)d_o, osb, osn, lse, nlse, delta, (bf16*)dq, H, N, scale, da);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, block, BWD_NST * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
                        osn, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, da);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb, osn,
-                       nlse, delta, (bf16*)dq, H, N, scale, da);
   } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)o,
+                       (const bf16*)d_o, osb, osn, lse, nlse, delta, (bf16*)dq, H, N, scale, da);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, BWD_NST * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
                        osn, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, da);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb, osn,
-                       nlse, delta, (bf16*)dq, H, N, scale, da);
   }
   return check_launch("xvit_attn_bwd");
 }
