@@ -46,3 +46,40 @@ def test_modules_have_reference_state_dict_keys():
     from types import SimpleNamespace
     enc = xvit.Encoder(SimpleNamespace(hidden_size=256, transformer=dict(num_heads=4, mlp_dim=512, dropout_rate=0.0, attention_dropout_rate=0.0, num_layers=2)))
     assert set(enc.state_dict()) == set(R.make_encoder_state_dict(256, 512, 2))
+
+
+def test_patch_embed_geometry_predicate_and_workspaces():
+    """Host-only entry points of the fused patch embedding and the fp8 attention: which geometries the gather kernels take
+    (include/xvit.h) and what scratch they ask for — no GPU needed."""
+    import ctypes as C
+    from xvit import _lib
+    lib = _lib.load()
+
+    def geom(B, M, vol, patch, cls=1):
+        g = _lib.PatchGeom()
+        g.B, g.M, (g.D, g.H, g.W), (g.dp, g.hp, g.wp), g.cls_rows = B, M, vol, patch, cls
+        return g
+
+    ok = lambda g, d: lib.xvit_patch_embed_supported(C.byref(g), d)   # noqa: E731
+    assert ok(geom(126, 2, (128, 128, 128), (16, 16, 16)), 768) == 1          # configs[1]
+    assert ok(geom(8, 2, (128, 128, 128), (8, 8, 8)), 768) == 1               # configs[4]
+    assert ok(geom(8, 4, (240, 240, 240), (16, 16, 16)), 768) == 0            # configs[2]: 15 patches per axis (64 % 15 != 0)
+    assert ok(geom(1, 1, (128, 128, 128), (16, 16, 16)), 768) == 0            # 513 rows: small-tile path
+    assert ok(geom(126, 2, (128, 128, 128), (16, 16, 16)), 192) == 0          # d not a multiple of 256
+    assert ok(geom(126, 2, (128, 128, 128), (16, 16, 4)), 768) == 0           # 8-byte runs
+    assert ok(geom(126, 2, (128, 128, 120), (16, 16, 16)), 768) == 0          # W not divisible
+    assert ok(geom(300, 2, (128, 128, 128), (16, 16, 16)), 768) == 0          # volume tensor beyond 2 GiB
+    assert ok(geom(126, 2, (128, 128, 128), (16, 16, 16), cls=2), 768) == 0
+    g = geom(126, 2, (128, 128, 128), (16, 16, 16))
+    ws = lib.xvit_patch_embed_wgrad_workspace_bytes(C.byref(g), 768)
+    assert ws > 0 and ws % (768 * 4096 * 4) == 0                              # split-K slabs of the [768, 4096] gradient
+    assert lib.xvit_patch_embed_wgrad_workspace_bytes(C.byref(geom(1, 1, (128, 128, 128), (16, 16, 16))), 768) == 0
+    # unsupported geometry: refused before any launch
+    bad = geom(1, 1, (128, 128, 128), (16, 16, 16))
+    assert lib.xvit_patch_embed_fwd(1, C.byref(bad), 1, 4096, None, None, 0, 1, 768, 768, None) < 0
+    assert b"not supported" in lib.xvit_last_error_string()
+    # fp8 attention scratch: q8 + k8 + v8t (B H Np 64 each) + scales, Np = N rounded up to 64
+    need = lib.xvit_attn_fp8_workspace_bytes(8, 12, 4097, 64)
+    assert 3 * 8 * 12 * 4160 * 64 <= need < 3.2 * 8 * 12 * 4160 * 64
+    assert lib.xvit_attn_fp8_workspace_bytes(8, 12, 4097, 32) == 0
+    assert lib.xvit_attn_fwd_fp8(None, None, None, 0, 0, None, 0, 0, None, 1, 1, 64, 64, 0.125, None, 0, None) < 0
