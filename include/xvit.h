@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define XVIT_VERSION 100 /* 0.1.0 */
+#define XVIT_VERSION 200 /* 0.2.0: ld_alt in xvit_layernorm_fwd/bwd, dropout in xvit_attn_*, xvit_patch_embed_*, xvit_attn_fwd_fp8, xvit_linear_f32, workspaces */
 
 enum { XVIT_OK = 0, XVIT_ERR_ARG = -1, XVIT_ERR_UNSUPPORTED = -2 };
 enum { XVIT_BF16 = 0, XVIT_F32 = 1 };
