@@ -28,6 +28,7 @@ struct GemmParams {
   float* slab;          // split-K partial sums [split][batch][M][N], else nullptr
   float* colsum;        // optional [N] fp32: += column sums of the stored C
   float drop_p, drop_inv; uint64_t drop_seed;   // dropout after the activation, before the residual (p == 0: off)
+  int aux_deriv;                 // aux holds GELU'(z) instead of z: ACT_GELU writes the derivative, ACT_DGELU multiplies by it
   int narrow_epi;                // force the 8-byte-per-lane epilogue (A/B measurements)
   int ncg;                       // gemm_big_kernel: column tiles per super-column of the tile walk
   // Patch rows gathered straight from the volume (xvit_patch_embed_*; reference model_cross.py:193, the einops rearrange
@@ -61,6 +62,10 @@ __device__ __forceinline__ uint32_t gather_sample_origin(const GemmParams::Patch
   return (uint32_t)(b * g.sBt + mod * g.sMd);
 }
 
+// compile-time activation codes of the wide epilogue kernels for aux_mode 1 (the public codes + p.aux_deriv everywhere else)
+constexpr int ACT_GELU_D = 3;    // C = gelu(z), aux <- gelu'(z)
+constexpr int ACT_MULAUX = 4;    // C = acc * aux
+
 // ---- the fused epilogue, shared by both tile kernels and the split-K reduce kernel -------------
 // v: 4 consecutive output columns of one row (fp32 accumulators).  Returns the value stored.
 template <int ACT, bool DROP = false>
@@ -68,16 +73,24 @@ __device__ __forceinline__ f32x4 epilogue_apply(const GemmParams& p, f32x4 v, in
                                                 bf16* aux) {
   if (bias) v += *(const f32x4*)(bias + col);
   if (ACT == XVIT_ACT_GELU) {
-    if (aux) {
-      bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+    f32x4 d;
+    const f32x4 zv = v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { float a_, d_; gelu_and_grad(zv[e], a_, d_); v[e] = a_; d[e] = d_; }
+    if (aux) {   // the pre-activation, or (aux_mode 1) the derivative the backward will multiply by
+      const f32x4 s = p.aux_deriv ? d : zv;
+      bf16x4 z = {f2bf(s[0]), f2bf(s[1]), f2bf(s[2]), f2bf(s[3])};
       *(bf16x4*)(aux + (int64_t)row * p.ldaux + col) = z;
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
   } else if (ACT == XVIT_ACT_DGELU) {
     const bf16x4 z = *(const bf16x4*)(aux + (int64_t)row * p.ldaux + col);
+    if (p.aux_deriv) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(bf2f(z[e]));
+      for (int e = 0; e < 4; ++e) v[e] *= bf2f(z[e]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= dgelu_f(bf2f(z[e]));
+    }
   }
   if (DROP) {   // mask keyed by (seed, batch-local element index): regenerated, never stored
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
@@ -564,16 +577,24 @@ __device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32
   } else {
     v += e.bias;
     if (ACT == XVIT_ACT_GELU) {
+      f32x4 d;
+      const f32x4 zv = v;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { float a_, d_; gelu_and_grad(zv[c], a_, d_); v[c] = a_; d[c] = d_; }
       if (e.has_aux) {
-        bf16x4 z = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
+        const f32x4 sv = p.aux_deriv ? d : zv;
+        bf16x4 z = {f2bf(sv[0]), f2bf(sv[1]), f2bf(sv[2]), f2bf(sv[3])};
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, z), e.raux, ok ? e.aux : OOB, 0, XVIT_EPI_STORE_AUX);
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
     } else if (ACT == XVIT_ACT_DGELU) {
       const bf16x4 z = __builtin_bit_cast(bf16x4, auxv);
+      if (p.aux_deriv) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] *= dgelu_f(bf2f(z[c]));
+        for (int c = 0; c < 4; ++c) v[c] *= bf2f(z[c]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] *= dgelu_f(bf2f(z[c]));
+      }
     }
     if (DROP) {
       const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
@@ -686,13 +707,22 @@ __device__ __forceinline__ u32x4_t pack_bf16x8(const f32x4& a, const f32x4& b) {
 
 // activation + dropout on 4 of the lane's 8 elements (columns col .. col + 3 of row `row`)
 template <int ACT, bool DROP>
-__device__ __forceinline__ void wide_half(const GemmParams& p, f32x4& v, const bf16x4 z, uint64_t idx) {
+__device__ __forceinline__ void wide_half(const GemmParams& p, f32x4& v, const bf16x4 z, uint64_t idx, u32x2_t& dpack) {
   if (ACT == XVIT_ACT_GELU) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] = gelu_f(v[c]);
+  } else if (ACT == ACT_GELU_D) {   // gelu and, packed to bf16 at once (registers), its derivative for the aux tensor
+    f32x4 d;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { float a_, d_; gelu_and_grad(v[c], a_, d_); v[c] = a_; d[c] = d_; }
+    const bf16x4 db = {f2bf(d[0]), f2bf(d[1]), f2bf(d[2]), f2bf(d[3])};
+    dpack = __builtin_bit_cast(u32x2_t, db);
   } else if (ACT == XVIT_ACT_DGELU) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] *= dgelu_f(bf2f(z[c]));
+  } else if (ACT == ACT_MULAUX) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] *= bf2f(z[c]);
   }
   if (DROP) {
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
@@ -710,9 +740,11 @@ __device__ __forceinline__ void wide_body(const GemmParams& p, WideEpi& e, f32x4
   const uint64_t idx = e.drop_base + (uint64_t)e.row * p.N + e.col;
   // the two halves one after the other (a scheduling fence between them): eight interleaved GELU / hash evaluations
   // need more temporaries than the allocator has next to the accumulators still waiting for their LDS pass
-  wide_half<ACT, DROP>(p, v0, bf16x4{z[0], z[1], z[2], z[3]}, idx);
-  if (ACT != XVIT_ACT_NONE || DROP) __builtin_amdgcn_sched_barrier(0);
-  wide_half<ACT, DROP>(p, v1, bf16x4{z[4], z[5], z[6], z[7]}, idx + 4);
+  u32x2_t d0 = {0u, 0u}, d1 = {0u, 0u};
+  wide_half<ACT, DROP>(p, v0, bf16x4{z[0], z[1], z[2], z[3]}, idx, d0);
+  if ((ACT != XVIT_ACT_NONE && ACT != ACT_MULAUX) || DROP) __builtin_amdgcn_sched_barrier(0);
+  wide_half<ACT, DROP>(p, v1, bf16x4{z[4], z[5], z[6], z[7]}, idx + 4, d1);
+  if (ACT == ACT_GELU_D && e.has_aux) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{d0[0], d0[1], d1[0], d1[1]}, e.raux, ok ? e.aux : OOB, 0, XVIT_EPI_STORE_AUX);
   __builtin_amdgcn_raw_buffer_store_b128(pack_bf16x8(v0, v1), e.rc, ok ? e.c : OOB, 0, XVIT_EPI_STORE_AUX);
 #pragma unroll
   for (int c = 0; c < 4; ++c) { e.csum0[c] += ok ? v0[c] : 0.f; e.csum1[c] += ok ? v1[c] : 0.f; }
@@ -731,7 +763,7 @@ __device__ __forceinline__ void wide_regions(const GemmParams& p, WideEpi& e, Wi
       for (int j = 0; j < 4; ++j) *(XVIT_LDS f32x4*)(slice + i * 4096 + woff[j]) = acc[(R >> 2) * 4 + i][j];
   }
   WideLoads nxt;
-  if constexpr (ACT == XVIT_ACT_DGELU && R < 7) wide_issue_aux(p, e, lc, nxt);
+  if constexpr ((ACT == XVIT_ACT_DGELU || ACT == ACT_MULAUX) && R < 7) wide_issue_aux(p, e, lc, nxt);
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int it = (R & 3) * 2 + b;   // 8-row group inside the 64-row pass
@@ -748,7 +780,7 @@ __device__ __forceinline__ void wide_epilogue(const GemmParams& p, WideEpi& e, c
                                               const uint32_t (&roffw)[2][2], float* colsum_dst) {
   WideCursor lc = {e.row, e.aux};
   WideLoads first;
-  if constexpr (ACT == XVIT_ACT_DGELU) wide_issue_aux(p, e, lc, first);
+  if constexpr (ACT == XVIT_ACT_DGELU || ACT == ACT_MULAUX) wide_issue_aux(p, e, lc, first);
   wide_regions<ACT, DROP, 0>(p, e, lc, first, acc, slice, woff, roffw);
   if (colsum_dst) {   // lanes l, l+8, ..., l+56 share their 8 columns
 #pragma unroll
@@ -1070,6 +1102,7 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   }
   XVIT_REQUIRE(!(a->accumulate && a->c_dtype != XVIT_F32), "xvit_gemm: accumulate needs fp32 C");
   XVIT_REQUIRE(a->act != XVIT_ACT_DGELU || a->aux, "xvit_gemm: ACT_DGELU needs aux (pre-activation)");
+  XVIT_REQUIRE(a->aux_mode == 0 || a->aux_mode == 1, "xvit_gemm: aux_mode must be 0 (aux = pre-activation) or 1 (aux = GELU')");
   if (a->aux) XVIT_REQUIRE(a->ldaux % 4 == 0 && a->ldaux >= a->N && (reinterpret_cast<uintptr_t>(a->aux) & 7) == 0, "xvit_gemm: bad aux layout");
   if (a->residual) XVIT_REQUIRE(a->ldr % 4 == 0 && a->ldr >= a->N && aligned16(a->residual), "xvit_gemm: bad residual layout");
   if (a->bias) XVIT_REQUIRE(aligned16(a->bias) && a->stride_bias % 4 == 0, "xvit_gemm: bias must be 16-byte aligned");
@@ -1095,6 +1128,7 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   XVIT_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "xvit_gemm: dropout_p must be in [0, 1)");
   p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
   p.narrow_epi = g_gemm_epi.load(std::memory_order_relaxed);
+  p.aux_deriv = a->aux_mode;
   p.ncg = 1;
   p.g.mode = 0;
   hipStream_t s = (hipStream_t)stream;
@@ -1111,6 +1145,8 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, XVIT_ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, XVIT_ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, XVIT_ACT_DGELU>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, ACT_GELU_D>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, true, ACT_MULAUX>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
   });
   if (big) {
     p.ntm = (a->M + TBM - 1) / TBM; p.ntn = (a->N + TBN - 1) / TBN;
@@ -1126,8 +1162,10 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
     const bool wide = !p.c_f32 && !p.slab && !p.res && p.seg_rows == 0 && !p.narrow_epi && p.drop_p == 0.f && a->layout != XVIT_GEMM_TN &&
                       ((p.N | (int)p.ldc | (int)p.ldaux) & 7) == 0 && (a->layout == XVIT_GEMM_NT ? p.act != XVIT_ACT_DGELU : p.act != XVIT_ACT_GELU);
     if (wide && a->layout == XVIT_GEMM_NT && p.act == XVIT_ACT_NONE) hipLaunchKernelGGL((gemm_big_kernel<false, false, XVIT_ACT_NONE>), grid, block, T_LDS, s, p);
+    else if (wide && a->layout == XVIT_GEMM_NT && p.aux_deriv) hipLaunchKernelGGL((gemm_big_kernel<false, false, ACT_GELU_D>), grid, block, T_LDS, s, p);
     else if (wide && a->layout == XVIT_GEMM_NT) hipLaunchKernelGGL((gemm_big_kernel<false, false, XVIT_ACT_GELU>), grid, block, T_LDS, s, p);
     else if (wide && p.act == XVIT_ACT_NONE) hipLaunchKernelGGL((gemm_big_kernel<false, true, XVIT_ACT_NONE>), grid, block, T_LDS, s, p);
+    else if (wide && p.aux_deriv) hipLaunchKernelGGL((gemm_big_kernel<false, true, ACT_MULAUX>), grid, block, T_LDS, s, p);
     else if (wide) hipLaunchKernelGGL((gemm_big_kernel<false, true, XVIT_ACT_DGELU>), grid, block, T_LDS, s, p);
     else if (a->layout == XVIT_GEMM_NT) hipLaunchKernelGGL((gemm_big_kernel<false, false, -1>), grid, block, T_LDS, s, p);
     else if (a->layout == XVIT_GEMM_NN) hipLaunchKernelGGL((gemm_big_kernel<false, true, -1>), grid, block, T_LDS, s, p);
@@ -1191,7 +1229,7 @@ static void pe_defaults(GemmParams& p) {
   p.sA = p.sB = p.sC = p.sBias = p.sR = p.sAux = 0;
   p.c_f32 = 1; p.act = XVIT_ACT_NONE; p.accumulate = 0;
   p.res_row_mod = 0; p.res_row_off = 0; p.seg_rows = 0; p.seg_skip = 0; p.row_off = 0;
-  p.drop_p = 0.f; p.drop_inv = 1.f; p.drop_seed = 0; p.narrow_epi = 1; p.split_k = 1;
+  p.drop_p = 0.f; p.drop_inv = 1.f; p.drop_seed = 0; p.narrow_epi = 1; p.split_k = 1; p.aux_deriv = 0;
 }
 
 static void pe_attrs() {

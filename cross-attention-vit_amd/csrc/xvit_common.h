@@ -143,6 +143,12 @@ __device__ __forceinline__ float gelu_f(float x) {
   gelu_parts(x, cdf, pdf);
   return x * cdf;
 }
+__device__ __forceinline__ void gelu_and_grad(float x, float& a, float& d) {   // a = gelu(x), d = gelu'(x): one exponential for both
+  float cdf, pdf;
+  gelu_parts(x, cdf, pdf);
+  a = x * cdf;
+  d = fmaf(x, pdf, cdf);
+}
 __device__ __forceinline__ float dgelu_f(float x) {
   float cdf, pdf;
   gelu_parts(x, cdf, pdf);

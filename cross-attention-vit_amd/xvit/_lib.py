@@ -16,7 +16,7 @@ class GemmArgs(C.Structure):
     """struct xvit_gemm_args (include/xvit.h)."""
     _fields_ = [(n, i32) for n in (
         "layout", "M", "N", "K", "batch", "c_dtype", "act", "accumulate", "split_k",
-        "res_row_mod", "res_row_off", "out_seg_rows", "out_seg_skip", "out_row_off", "reserved")] + [
+        "res_row_mod", "res_row_off", "out_seg_rows", "out_seg_skip", "out_row_off", "aux_mode")] + [
         (n, vp) for n in ("A", "B", "C", "bias", "residual", "aux")] + [
         (n, i64) for n in ("lda", "ldb", "ldc", "ldr", "ldaux",
                            "stride_a", "stride_b", "stride_c", "stride_bias", "stride_r", "stride_aux")] + [

@@ -250,13 +250,13 @@ def _linear(x_b, w_s, *, bias=None, residual=None, act=ops.ACT_NONE, aux=None, o
                     split_k=_skinny_split(x_b.shape[0], w_s.shape[0], w_s.shape[1]), **kw)
 
 
-def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None, colsum=None, dropout=None):
+def _dgrad(dy_b, w_s, *, act=ops.ACT_NONE, aux=None, colsum=None, dropout=None, aux_mode=0):
     """dx = dy W (+ GELU' / dropout epilogue).  `colsum` (bias gradient of the Linear that produced dx's pre-image)
     is accumulated by the GEMM epilogue itself on every tile path."""
     m, n, k = dy_b.shape[0], w_s.shape[1], w_s.shape[0]
     dx = torch.empty(m, n, dtype=torch.bfloat16, device=dy_b.device)
     fused = None if ops.DETERMINISTIC else colsum          # the epilogue's column sums meet in fp32 atomics
-    ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=fused, dropout=dropout, split_k=_skinny_split(m, n, k))
+    ops.gemm(ops.NN, dy_b, w_s, dx, act=act, aux=aux, colsum=fused, dropout=dropout, split_k=_skinny_split(m, n, k), aux_mode=aux_mode)
     if colsum is not None and fused is None:
         ops.colsum(dx, out=colsum, accumulate=True)        # fixed-order two-pass sum of the stored (bf16) values
     return dx
@@ -282,6 +282,11 @@ def _f32c(t):
 # ------------------------------------------------------------------------------------------
 
 
+# The all-token FFNs save gelu'(pre-activation) instead of the pre-activation itself (xvit_gemm aux_mode 1): the forward epilogue
+# has the exponential at hand anyway, and the GELU' dgrad epilogue becomes a multiply.  XVIT_GELU_AUX=z restores the old form.
+AUX_MODE = 0 if os.environ.get("XVIT_GELU_AUX", "deriv") == "z" else 1
+
+
 def _attn_fwd(qkv, B, N, H, scale, p=0.0, seed=0):
     """Forward attention of the all-token blocks.  XVIT_ATTN_FP8=1 (opt-in, SURVEY.md 8 / configs[4]) runs QK^T and P.V on the
     MX-fp8 matrix instruction where the kernel applies (d_h = 64, no probability dropout): ~5e-2 output error instead of 2e-3
@@ -302,7 +307,7 @@ def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln
     x1 = _linear(o, wo_s, bias=bo, residual=x, out_dtype=torch.float32, dropout=_dp(p_out, seeds[0]))
     h2, mu2, rs2 = ops.layernorm_fwd(x1, ln2w, ln2b, eps)
     z = torch.empty(x.shape[0], w1_s.shape[0], dtype=torch.bfloat16, device=x.device)
-    a = _linear(h2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z, dropout=_dp(p_ffn, seeds[1]))
+    a = _linear(h2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z, dropout=_dp(p_ffn, seeds[1]), aux_mode=AUX_MODE)     # z: gelu'(pre-activation)
     x2 = _linear(a, w2_s, bias=b2, residual=x1, out_dtype=torch.float32, dropout=_dp(p_ffn, seeds[2]))
     return x2, (x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a)
 
@@ -317,7 +322,7 @@ def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w
     g["b1"] = zero[6 * d:]
     dyb = _masked(ops.cast_bf16(dy), p_ffn, seeds[2])        # d(FFN out) = dy * mask
     # FFN
-    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"], dropout=_dp(p_ffn, seeds[1]))
+    dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"], dropout=_dp(p_ffn, seeds[1]), aux_mode=AUX_MODE)
     g["w2"] = _wgrad(dyb, a)
     dh2 = _dgrad(dz, w1_s)
     g["w1"] = _wgrad(dz, h2)
@@ -724,7 +729,7 @@ class FeedForwardFn(Function):
         w1_s, w2_s = SHADOWS.get(w1), SHADOWS.get(w2)
         z = torch.empty(x2.shape[0], w1.shape[0], dtype=torch.bfloat16, device=x.device)
         seeds = drop_seeds(2) if p > 0.0 else (0, 0)
-        a = _linear(x2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z, dropout=_dp(p, seeds[0]))
+        a = _linear(x2, w1_s, bias=b1, act=ops.ACT_GELU, aux=z, dropout=_dp(p, seeds[0]), aux_mode=AUX_MODE)
         y = _linear(a, w2_s, bias=b2, out_dtype=torch.float32, dropout=_dp(p, seeds[1]))
         ctx.save_for_backward(x2, z, a, w1_s, w2_s)
         ctx.meta = (x.shape, x.dtype, p, seeds)
@@ -737,7 +742,7 @@ class FeedForwardFn(Function):
         dyb = _as_bf16_2d(dy)
         if p > 0.0:
             dyb = ops.dropout(dyb, p, seeds[1])
-        dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, dropout=_dp(p, seeds[0]))
+        dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, dropout=_dp(p, seeds[0]), aux_mode=AUX_MODE)
         dx = _dgrad(dz, w1_s).reshape(shape)
         dW1, dW2 = _wgrad(dz, x2), _wgrad(dyb, a)
         _join_wgrads(dyb.device)

@@ -87,7 +87,7 @@ def _rows2d(t):
 
 
 def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NONE, accumulate=False,
-         split_k=1, res_row_mod=0, res_row_off=0, out_seg=(0, 0, 0), M=None, N=None, K=None, colsum=None, dropout=None):
+         split_k=1, res_row_mod=0, res_row_off=0, out_seg=(0, 0, 0), M=None, N=None, K=None, colsum=None, dropout=None, aux_mode=0):
     """C = op(A) op(B) with the fused epilogue of include/xvit.h.  2-D tensors, or 3-D
     [batch, rows, cols] for a strided batch (all of A, B, C and optional bias 2-D / residual /
     aux 3-D then carry the batch in dim 0)."""
@@ -105,6 +105,7 @@ def gemm(layout, A, B, C_out, *, bias=None, residual=None, aux=None, act=ACT_NON
     assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16
     a.c_dtype, a.act, a.accumulate, a.split_k = _dt(C_out), act, int(bool(accumulate)), split_k
     a.res_row_mod, a.res_row_off = res_row_mod, res_row_off
+    a.aux_mode = aux_mode             # 1: aux carries gelu'(z) instead of z (include/xvit.h)
     a.out_seg_rows, a.out_seg_skip, a.out_row_off = out_seg
     a.A, a.B, a.C = _ptr(A), _ptr(B), _ptr(C_out)
     a.lda, a.ldb, a.ldc = _rows2d(A2), _rows2d(B2), _rows2d(C2)

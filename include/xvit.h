@@ -70,7 +70,9 @@ typedef struct xvit_gemm_args {
   /* output row = row + (row / out_seg_rows) * out_seg_skip + out_row_off when out_seg_rows > 0
      (patch rows -> token rows that leave room for the CLS row, model_cross.py:195-196) */
   int32_t out_seg_rows, out_seg_skip, out_row_off;
-  int32_t reserved;
+  int32_t aux_mode;   /* 0: aux = the pre-activation z (ACT_GELU writes it, ACT_DGELU reads it and evaluates gelu');
+                         1: aux = gelu'(z): ACT_GELU writes the derivative (one more fma next to the shared exponential) and
+                            ACT_DGELU only multiplies by it — the backward epilogue loses its erf / exp evaluation */
   const void* A; const void* B; void* C;
   const float* bias;     /* [N] fp32 or NULL */
   const float* residual; /* fp32 [*, N] or NULL */

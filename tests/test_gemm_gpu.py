@@ -87,6 +87,31 @@ def test_epilogue_bias_gelu_aux(M, N, K):
     assert_close(C, _gelu(z), "gelu")
 
 
+@pytest.mark.parametrize("M,N,K,drop", [(513, 768, 192, 0.0), (2600, 3072, 128, 0.0), (4100, 2560, 64, 0.0), (33000, 3072, 64, 0.0), (2600, 3072, 128, 0.25), (130, 192, 64, 0.0)])
+def test_gelu_saves_its_derivative_and_dgrad_multiplies(M, N, K, drop):
+    """aux_mode 1 (what the FFNs use): the GELU epilogue writes gelu'(z) instead of z, the dgrad epilogue multiplies by it —
+    on the wide 256x256 kernels (no dropout), the narrow ones (dropout) and the 128x128 kernel (small shapes)."""
+    ops = _ops()
+    a, w, b = rt(randn(M, K, seed=1)), rt(randn(N, K, seed=2, scale=K ** -0.5)), randn(N, seed=3, scale=0.1)
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    D = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    dp = (drop, 1234) if drop > 0 else None
+    ops.gemm(ops.NT, a.to(dev(), torch.bfloat16), w.to(dev(), torch.bfloat16), C, bias=b.to(dev()), act=ops.ACT_GELU, aux=D, aux_mode=1, dropout=dp)
+    z = a @ w.T + b
+    assert_close(D, _dgelu(z), "saved gelu'")
+    if drop == 0.0:
+        assert_close(C, _gelu(z), "gelu")
+    # backward: dz = (dy W2) * saved derivative, with the column sums of the result
+    F = 256
+    dy, w2 = rt(randn(M, F, seed=4)), rt(randn(F, N, seed=5, scale=F ** -0.5))
+    dz = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    cs = torch.zeros(N, device=dev())
+    ops.gemm(ops.NN, dy.to(dev(), torch.bfloat16), w2.to(dev(), torch.bfloat16), dz, act=ops.ACT_DGELU, aux=D, aux_mode=1, colsum=cs)
+    ref = (dy @ w2) * D.float().cpu()
+    assert_close(dz, ref, "dgrad x saved derivative")
+    assert_close(cs, ref.sum(0), "colsum")
+
+
 def test_epilogue_dgelu():
     ops = _ops()
     M, N, K = 260, 192, 768

@@ -3,7 +3,7 @@
 wgrad), timed per tile kernel, variants interleaved in one process (HIP events, random bf16 operands).  Prints the time,
 the algorithmic TFLOP/s and the algorithmic HBM GB/s (compulsory operand + epilogue bytes) of every case.
 
-    python tools/gemm_model_bench.py [batch] [variant ...]     variants: auto narrow tile128
+    python tools/gemm_model_bench.py [batch] [variant ...]     variants: auto narrow tile128 auxz g1..g12
 """
 import os
 import sys
@@ -18,6 +18,9 @@ from xvit.functional import _wgrad_split  # noqa: E402
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 126
 T = B * 513
+
+
+AUX = [1]     # xvit_gemm aux_mode of the GELU / GELU' epilogues: 1 = the saved tensor is gelu'(z) (what the model uses), 0 = z (variant "auxz")
 
 
 def bf(*shape):
@@ -39,7 +42,7 @@ def cases():
             kw["residual"] = torch.randn(M, N, device=dev); byt += M * N * 4
         if gelu:
             kw["act"] = ops.ACT_GELU; kw["aux"] = torch.empty(M, N, dtype=torch.bfloat16, device=dev); byt += M * N * 2
-        out.append((label, lambda: ops.gemm(ops.NT, A, W, C, **kw), 2.0 * M * N * K, byt))
+        out.append((label, lambda: ops.gemm(ops.NT, A, W, C, **kw, **({"aux_mode": AUX[0]} if gelu else {})), 2.0 * M * N * K, byt))
 
     def nn(label, M, N, K, dgelu=False):
         A, W = bf(M, K), bf(K, N)
@@ -48,7 +51,7 @@ def cases():
         byt = M * K * 2 + N * K * 2 + M * N * 2
         if dgelu:
             kw["act"] = ops.ACT_DGELU; kw["aux"] = bf(M, N); kw["colsum"] = torch.zeros(N, device=dev); byt += M * N * 2
-        out.append((label, lambda: ops.gemm(ops.NN, A, W, C, **kw), 2.0 * M * N * K, byt))
+        out.append((label, lambda: ops.gemm(ops.NN, A, W, C, **kw, **({"aux_mode": AUX[0]} if dgelu else {})), 2.0 * M * N * K, byt))
 
     def tn(label, M, N, K):
         A, Bm = bf(K, M), bf(K, N)
@@ -74,7 +77,7 @@ def cases():
     return out
 
 
-VARIANTS = {"auto": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", 0)), "narrow": (("gemm_tile", 0), ("gemm_epilogue", 1)), "tile128": (("gemm_tile", 1), ("gemm_epilogue", 0)),
+VARIANTS = {"auto": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", 0)), "auxz": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", 0)), "narrow": (("gemm_tile", 0), ("gemm_epilogue", 1)), "tile128": (("gemm_tile", 1), ("gemm_epilogue", 0)),
             **{f"g{n}": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", n)) for n in (1, 2, 3, 4, 6, 12)}}
 
 
@@ -90,6 +93,7 @@ def main():
             for v in names:
                 for k_, v_ in VARIANTS[v]:
                     ops.set_option(k_, v_)
+                AUX[0] = 0 if v == "auxz" else 1
                 fn(); fn()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()

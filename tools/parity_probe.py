@@ -73,7 +73,11 @@ def main():
             line("out-proj + res -> x1 (f32)", x1, cpu(o) @ q(sd[P + ".attn.fn.to_out.0.weight"]).T + sd[P + ".attn.fn.to_out.0.bias"] + cpu(x2d))
             line("LN2 -> h2 (bf16)", h2, q(R.layer_norm(cpu(x1), sd[P + ".ffn.norm.weight"], sd[P + ".ffn.norm.bias"])))
             pre = cpu(h2) @ q(sd[P + ".ffn.fn.net.0.weight"]).T + sd[P + ".ffn.fn.net.0.bias"]
-            line("FFN1 pre-act z (bf16)", z, q(pre))
+            if XF.AUX_MODE == 1:   # the FFN saves gelu'(z): Phi(z) + z phi(z)
+                dg = 0.5 * (1 + torch.erf(pre / 2 ** 0.5)) + pre * torch.exp(-0.5 * pre * pre) / (2 * torch.pi) ** 0.5
+                line("FFN1 saved gelu'(z) (bf16)", z, q(dg))
+            else:
+                line("FFN1 pre-act z (bf16)", z, q(pre))
             line("FFN1 GELU a (bf16)", a_, q(R.gelu(pre)))
             line("FFN2 + res -> x2 (f32)", x2, cpu(a_) @ q(sd[P + ".ffn.fn.net.3.weight"]).T + sd[P + ".ffn.fn.net.3.bias"] + cpu(x1))
             return x2.reshape(B, N, d)
