@@ -289,6 +289,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
   const int nbatch = gridDim.z / p.split_k;
   float* part = p.slab ? p.slab + ((int64_t)split * nbatch + batch) * (int64_t)p.M * p.N : nullptr;
 
+  // column sums of the stored values: a lane's 4 columns are the same in every row it visits, so they are summed in registers,
+  // then over the 4 lanes that share the columns, and reach memory as ONE atomic per column and wave (per-element atomics made a
+  // 4104 x 3072 GELU' dgrad take 476 us instead of 34)
+  f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};
+  const int col = n0 + wc * 64 + (lane & 15) * 4;
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
@@ -299,7 +304,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         for (int r = 0; r < 4; ++r)
           slab[(mi * 16 + (lane >> 4) * 4 + r) * EPI_LD + j * 16 + (lane & 15)] = acc[pass * 2 + mi][j][r];
     const int row_base = m0 + wr * 64 + pass * 32;
-    const int col = n0 + wc * 64 + (lane & 15) * 4;
 #pragma unroll 1
     for (int it = 0; it < 8; ++it) {
       const int rl = it * 4 + (lane >> 4);
@@ -309,13 +313,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         if (part) {
           *(f32x4*)(part + (int64_t)row * p.N + col) = v;   // split-K partial: epilogue runs in the reduce kernel
         } else {
-          const f32x4 o = epilogue_apply_rt(p, v, row, col, cb, bias, res, aux);
-          if (csum) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) unsafeAtomicAdd(csum + col + e, o[e]);
-          }
+          cs4 += epilogue_apply_rt(p, v, row, col, cb, bias, res, aux);
         }
       }
+    }
+  }
+  if (csum && !part) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float t = cs4[e];
+      t += __shfl_xor(t, 16);
+      t += __shfl_xor(t, 32);
+      cs4[e] = t;
+    }
+    if (lane < 16 && col < p.N) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) unsafeAtomicAdd(csum + col + e, cs4[e]);
     }
   }
 }

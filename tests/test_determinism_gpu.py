@@ -61,8 +61,9 @@ def test_deterministic_mode_matches_default_mode():
     finally:
         ops.set_deterministic(False)
     for k in g_atomic:
-        # bias gradients taken from the GEMM epilogue sum fp32 values, the two-pass form the stored bf16 ones: 1e-3; the rest 1e-5
-        tol = 2e-3 if k.endswith("net.0.bias") else 1e-5
+        # bias gradients taken from the GEMM epilogue sum fp32 values, the two-pass form the stored bf16 ones: up to half a bf16 ulp
+        # (2^-9 = 2e-3) per value, and the fusion's single-token FFN sums only B = 4 of them — nothing averages; the rest 1e-5
+        tol = 4e-3 if k.endswith("net.0.bias") else 1e-5
         assert rel(g_det[k], g_atomic[k]) < tol or float(g_atomic[k].abs().max()) < 1e-6, (k, rel(g_det[k], g_atomic[k]))
 
 
