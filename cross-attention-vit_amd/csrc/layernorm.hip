@@ -179,10 +179,18 @@ __global__ void ln_bwd_reduce_kernel(const float* __restrict__ part, float* __re
 
 using namespace xvit;
 
+// Every block adds its dgamma / dbeta partials to the SAME d addresses: more blocks = atomic contention (measured slower beyond
+// 768 at 64 k rows).  With few rows the atomics dominate outright — at 4104 rows (the reference's batch 8) one row per wave on 768
+// blocks took 26 us, 768 adds queueing on every address — so a block takes at least 16 rows (4 per wave).
+static int ln_bwd_grid(int rows) {
+  int g = (rows + 4 * LNB_WAVES - 1) / (4 * LNB_WAVES);
+  if (g > 768) g = 768;
+  return g < 1 ? 1 : g;
+}
+
 extern "C" int64_t xvit_layernorm_bwd_workspace_bytes(int rows, int d) {
   if (rows <= 0 || d <= 0) return 0;
-  int g = (rows + LNB_WAVES - 1) / LNB_WAVES;
-  if (g > 768) g = 768;
+  const int g = ln_bwd_grid(rows);
   return (int64_t)g * 4 * d * (int64_t)sizeof(float);
 }
 
@@ -219,8 +227,7 @@ extern "C" int xvit_layernorm_bwd(const void* dy, int64_t lddy, const float* x, 
   XVIT_REQUIRE(!x_alt || (seq_len > 0 && ld_alt >= d && ld_alt % 4 == 0), "xvit_layernorm_bwd: x_alt needs seq_len > 0 and ld_alt >= d, a multiple of 4");
   XVIT_REQUIRE(!dressum || dres, "xvit_layernorm_bwd: dressum needs dres");
   hipStream_t s = (hipStream_t)stream;
-  int g = (rows + LNB_WAVES - 1) / LNB_WAVES;
-  if (g > 768) g = 768;  // every block adds its dgamma/dbeta partials to the SAME d addresses: more blocks = atomic contention (measured slower)
+  const int g = ln_bwd_grid(rows);
   XVIT_REQUIRE(!workspace || workspace_bytes >= (int64_t)g * 4 * d * (int64_t)sizeof(float), "xvit_layernorm_bwd: workspace too small (%lld bytes)",
                (long long)workspace_bytes);
   const dim3 grid(g), block(LNB_WAVES * 64);

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "cross-attention-vit_amd"))
 from xvit import ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-rows, d = 126 * 513, 768
+rows, d = (int(sys.argv[1]) if len(sys.argv) > 1 else 126) * 513, 768
 x = torch.randn(rows, d, device=dev)
 g, b = torch.randn(d, device=dev), torch.randn(d, device=dev)
 dy = torch.randn(rows, d, device=dev).bfloat16()
