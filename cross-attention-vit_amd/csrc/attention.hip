@@ -511,7 +511,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
 // ------------------------------------------------------------------------------------------
 constexpr int DKV_STAGE = 2 * IMG_BYTES + 512;  // Q image | dO image | nlse[64] | delta[64]  (all four arrive by LDS-DMA)
 
-// (198 VGPRs: two blocks per CU; bounding it to 168 for a third spills and measured 7 % slower)
+// (198 VGPRs: two blocks per CU; bounding it to 168 for a third spills and measured 7 % slower; keeping the query-block loop
+// rolled gives 162 VGPRs without spills and three blocks per CU: 552 vs 563 us at B = 126, N = 513, but 50.4 vs 47.0 us at B = 8
+// and 1466 vs 1439 us at N = 4097 — not kept)
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                               int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
