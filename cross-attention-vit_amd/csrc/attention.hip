@@ -318,6 +318,9 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
         for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[qb][1][i]);
       }
       mx = half_max(mx);
+      // (Deferring the rescale until the max has grown by 2^6 — p up to 64 instead of 1 — measured 525 -> 505 us at N = 4097 and nothing at
+      // N = 513, and moved the model's logits from 6.7e-3 to 1.3e-2 off the bf16-emulating oracle, whose P is rounded relative to the
+      // exact running max: not kept.)
       if (__any(mx > m_run[qb])) {   // some row's running max moved: rescale (otherwise alpha == 1 exactly, skip the pass)
         const float m_new = fmaxf(m_run[qb], mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
