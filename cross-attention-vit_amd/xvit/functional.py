@@ -188,10 +188,12 @@ def _dp(p, seed):
 
 
 def _wgrad_split(m, n, k):
-    """Split-K factor for a TN wgrad: enough workgroups to fill 256 CUs, >= 8 K-steps each."""
+    """Split-K factor for a TN wgrad: enough workgroups to fill 256 CUs, but >= 16 K-steps each on the 256x256 tiles (at the
+    reference's batch 8 — 64 K-steps in all — 16 splits of 4 steps cost 29 us per d x d gradient where 4 of 16 cost 21: prologue,
+    epilogue and slab traffic per split; tools/gemm_model_bench.py 8)."""
     if m >= 256 and n >= 256:   # 256x256 tiles, one block per CU
         tiles = ((m + 255) // 256) * ((n + 255) // 256)
-        return max(1, min(256 // max(tiles, 1), ((k + 63) // 64) // 4, 16))
+        return max(1, min(256 // max(tiles, 1), ((k + 63) // 64) // 16, 16))
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
     return max(1, min(512 // max(tiles, 1), ((k + 63) // 64) // 8, 32))
 
