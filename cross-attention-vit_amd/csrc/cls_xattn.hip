@@ -107,8 +107,8 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_bwd_kernel(const bf16* _
                                                                    const bf16* __restrict__ v, int64_t sb, int64_t sn,
                                                                    const float* __restrict__ p, const bf16* __restrict__ d_o, int64_t lddo,
                                                                    float* __restrict__ dq, int64_t lddq, bf16* __restrict__ dk,
-                                                                   bf16* __restrict__ dv, int H, int N, float scale, float drop_p,
-                                                                   uint64_t drop_seed) {
+                                                                   bf16* __restrict__ dv, float* __restrict__ coef, int H, int N, float scale,
+                                                                   float drop_p, uint64_t drop_seed) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* ds = (float*)smem_raw;            // [N] dp -> ds
   float* red = ds + ((N + 3) & ~3);
@@ -151,8 +151,17 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_bwd_kernel(const bf16* _
       okk[e] = f2bf(dsn * qv[e]);
       ovv[e] = f2bf(pr * gov[e]);
     }
-    *(bf16x8*)(dk + boff + (int64_t)n * sn + part * 8) = okk;
-    *(bf16x8*)(dv + boff + (int64_t)n * sn + part * 8) = ovv;
+    if (dk) {
+      *(bf16x8*)(dk + boff + (int64_t)n * sn + part * 8) = okk;
+      *(bf16x8*)(dv + boff + (int64_t)n * sn + part * 8) = ovv;
+    }
+    // dK and dV of this (b, head) are rank one — dk[n] = dsn q, dv[n] = pr dO: the two coefficients are all the K/V path's
+    // backward needs (xattn_kv_dgrad_kernel / xattn_kv_wgrad_kernel below), coef[b][n][head] = dsn, coef[b][n][H + head] = pr
+    if (coef && part == 0) {
+      float* c = coef + ((int64_t)b * N + n) * (2 * H);
+      c[head] = dsn;
+      c[H + head] = pr;
+    }
   }
 #pragma unroll
   for (int e = 0; e < 8; ++e) part_q[slice * 64 + part * 8 + e] = acc[e];
@@ -162,6 +171,95 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_bwd_kernel(const bf16* _
 #pragma unroll 8
     for (int s = 0; s < 32; ++s) r += part_q[s * 64 + tid];
     dq[(int64_t)b * lddq + head * XA_DH + tid] = r;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The K/V path's backward in its low-rank form.  For one sample, dkv[n, :] = sum_h (dsn[n,h] q_h | pr[n,h] dO_h) has rank <= 2 H,
+// so the gradient of the normed tokens,  dhn[n, :] = dk[n, :] Wk + dv[n, :] Wv = sum_j coef[n, j] R[j, :]  with
+// R[h, :] = q_h Wk[64 h .. 64 h + 63, :],  R[H + h, :] = dO_h Wv[64 h .., :]   (2 H x d, fp32, per sample: 2 H small products the host runs),
+// and the weight gradient,  dWk[64 h + e, :] = sum_b q[b,h,e] T[b, h, :],  T[b, j, :] = sum_n coef[b, n, j] hn[b, n, :],
+// need no [B N, 2 d] tensor, no K = 2 d GEMMs (2 x 152 GFLOP per fusion at configs[1]) and no column-sum pass: one kernel writes
+// dhn (99 MB), one reads hn (99 MB), both with 2 H = 24 fma per element.  Block = (row slice, sample); a thread owns 4 columns.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int XKV_MAXJ = 32;    // 2 H <= 32
+
+constexpr int XKV_ROWS = 64;    // rows of coefficients staged in LDS at a time (64 x 32 floats = 8 KiB)
+
+// stage coef[b][n0 .. n0 + rows)[0 .. J) into LDS rows of J2 floats (zero padded): every thread then reads a row's coefficients
+// as broadcast ds_read_b128 instead of 2 H global loads
+template <int J2>
+__device__ __forceinline__ void xkv_stage(float* lds, const float* __restrict__ coef, int64_t row0, int rows, int J) {
+  for (int i = threadIdx.x; i < rows * J2; i += blockDim.x) {
+    const int r = i / J2, j = i - r * J2;
+    lds[i] = j < J ? coef[(row0 + r) * J + j] : 0.f;
+  }
+}
+
+template <int J2>   // J2 = 2 H rounded up to a multiple of 8 (register-array bound)
+__global__ __launch_bounds__(256) void xattn_kv_dgrad_kernel(const float* __restrict__ coef, const float* __restrict__ R /*[2 H][B][d]*/,
+                                                             bf16* __restrict__ dhn, int64_t lddh, int H, int N, int d, int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) float cl[XKV_ROWS * J2];
+  const int b = blockIdx.y, tid = threadIdx.x, J = 2 * H;
+  const int n0 = blockIdx.x * rows_per_block, n1 = min(N, n0 + rows_per_block);
+  const int c0 = 4 * tid;                      // d <= 1024: one 4-column group per thread (host-checked)
+  f32x4 r[J2];
+#pragma unroll
+  for (int j = 0; j < J2; ++j) r[j] = (j < J && c0 < d) ? *(const f32x4*)(R + ((int64_t)j * gridDim.y + b) * d + c0) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int nb = n0; nb < n1; nb += XKV_ROWS) {
+    const int rows = min(XKV_ROWS, n1 - nb);
+    __syncthreads();
+    xkv_stage<J2>(cl, coef, (int64_t)b * N + nb, rows, J);
+    __syncthreads();
+    if (c0 < d) {
+      for (int rr = 0; rr < rows; ++rr) {
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j4 = 0; j4 < J2; j4 += 4) {
+          const f32x4 cf = *(const f32x4*)(cl + rr * J2 + j4);   // same address on every lane: an LDS broadcast
+          o += cf[0] * r[j4] + cf[1] * r[j4 + 1] + cf[2] * r[j4 + 2] + cf[3] * r[j4 + 3];
+        }
+        const bf16x4 ob = {f2bf(o[0]), f2bf(o[1]), f2bf(o[2]), f2bf(o[3])};
+        *(bf16x4*)(dhn + ((int64_t)b * N + nb + rr) * lddh + c0) = ob;
+      }
+    }
+  }
+}
+
+template <int J2>
+__global__ __launch_bounds__(256) void xattn_kv_wgrad_kernel(const float* __restrict__ coef, const bf16* __restrict__ hn, int64_t ldh,
+                                                             float* __restrict__ part /*[slices][2 H][B][d]*/, int H, int N, int d, int rows_per_block) {
+  __shared__ __attribute__((aligned(16))) float cl[XKV_ROWS * J2];
+  const int b = blockIdx.y, tid = threadIdx.x, J = 2 * H;
+  const int n0 = blockIdx.x * rows_per_block, n1 = min(N, n0 + rows_per_block);
+  const int c0 = 4 * tid;
+  f32x4 T[J2];
+#pragma unroll
+  for (int j = 0; j < J2; ++j) T[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int nb = n0; nb < n1; nb += XKV_ROWS) {
+    const int rows = min(XKV_ROWS, n1 - nb);
+    __syncthreads();
+    xkv_stage<J2>(cl, coef, (int64_t)b * N + nb, rows, J);
+    __syncthreads();
+    if (c0 < d) {
+      bf16x4 hv = *(const bf16x4*)(hn + ((int64_t)b * N + nb) * ldh + c0);
+      for (int rr = 0; rr < rows; ++rr) {
+        const f32x4 x = {bf2f(hv[0]), bf2f(hv[1]), bf2f(hv[2]), bf2f(hv[3])};
+        if (rr + 1 < rows) hv = *(const bf16x4*)(hn + ((int64_t)b * N + nb + rr + 1) * ldh + c0);   // next row in flight under the fmas
+#pragma unroll
+        for (int j4 = 0; j4 < J2; j4 += 4) {
+          const f32x4 cf = *(const f32x4*)(cl + rr * J2 + j4);
+          T[j4] += cf[0] * x; T[j4 + 1] += cf[1] * x; T[j4 + 2] += cf[2] * x; T[j4 + 3] += cf[3] * x;
+        }
+      }
+    }
+  }
+  if (c0 < d) {
+    float* dst = part + (((int64_t)blockIdx.x * J) * gridDim.y + b) * d + c0;
+#pragma unroll
+    for (int j = 0; j < J2; ++j)
+      if (j < J) *(f32x4*)(dst + (int64_t)j * gridDim.y * d) = T[j];
   }
 }
 
@@ -192,10 +290,10 @@ extern "C" int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const float* q_f32
 }
 
 extern "C" int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t sb, int64_t sn, const float* p, const void* d_o,
-                                  int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, int B, int H, int N, int dh, float scale,
+                                  int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, float* coef, int B, int H, int N, int dh, float scale,
                                   float drop_p, uint64_t drop_seed, xvit_stream_t stream) {
   XVIT_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "xvit_cls_xattn_bwd: dropout_p must be in [0, 1)");
-  XVIT_REQUIRE(q && k && v && p && d_o && dq && dk && dv, "xvit_cls_xattn_bwd: null pointer");
+  XVIT_REQUIRE(q && k && v && p && d_o && dq && ((dk && dv) || coef) && (!dk == !dv), "xvit_cls_xattn_bwd: null pointer (dk and dv together, or coef)");
   XVIT_REQUIRE(dh == XA_DH, "xvit_cls_xattn_bwd: head dim %d unsupported (only 64)", dh);
   XVIT_REQUIRE(B > 0 && H > 0 && N > 0 && B <= 65535, "xvit_cls_xattn_bwd: bad B/H/N");
   XVIT_REQUIRE(ldq % 8 == 0 && lddo % 8 == 0 && sb % 8 == 0 && sn % 8 == 0, "xvit_cls_xattn_bwd: strides must be multiples of 8 elements");
@@ -207,6 +305,45 @@ extern "C" int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, con
     attr = lds;
   }
   hipLaunchKernelGGL(cls_xattn_bwd_kernel, dim3(H, B), dim3(XA_THREADS), lds, (hipStream_t)stream, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, sb,
-                     sn, p, (const bf16*)d_o, lddo, dq, lddq, (bf16*)dk, (bf16*)dv, H, N, scale, drop_p, drop_seed);
+                     sn, p, (const bf16*)d_o, lddo, dq, lddq, (bf16*)dk, (bf16*)dv, coef, H, N, scale, drop_p, drop_seed);
   return check_launch("xvit_cls_xattn_bwd");
+}
+
+static int xkv_slices(int B, int N, int target = 1024) {   // row slices per sample: ~target blocks, at least 32 rows each
+  int s = (target + B - 1) / B;
+  if (s > (N + 31) / 32) s = (N + 31) / 32;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int xvit_xattn_kv_dgrad(const float* coef, const float* R, void* dhn, int64_t lddh, int B, int H, int N, int d, xvit_stream_t stream) {
+  XVIT_REQUIRE(coef && R && dhn, "xvit_xattn_kv_dgrad: null pointer");
+  XVIT_REQUIRE(B > 0 && B <= 65535 && N > 0 && H > 0 && 2 * H <= XKV_MAXJ && d % 4 == 0 && d <= 1024, "xvit_xattn_kv_dgrad: need 2 H <= %d, d %% 4 == 0 and d <= 1024 (B=%d H=%d N=%d d=%d)", XKV_MAXJ, B, H, N, d);
+  XVIT_REQUIRE(lddh % 4 == 0 && lddh >= d && ((uintptr_t)R & 15) == 0 && ((uintptr_t)dhn & 7) == 0, "xvit_xattn_kv_dgrad: lddh must be a multiple of 4 and >= d, pointers aligned");
+  const int slices = xkv_slices(B, N), rpb = (N + slices - 1) / slices;
+  const dim3 grid(slices, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (2 * H <= 8) hipLaunchKernelGGL((xattn_kv_dgrad_kernel<8>), grid, block, 0, s, coef, R, (bf16*)dhn, lddh, H, N, d, rpb);
+  else if (2 * H <= 16) hipLaunchKernelGGL((xattn_kv_dgrad_kernel<16>), grid, block, 0, s, coef, R, (bf16*)dhn, lddh, H, N, d, rpb);
+  else if (2 * H <= 24) hipLaunchKernelGGL((xattn_kv_dgrad_kernel<24>), grid, block, 0, s, coef, R, (bf16*)dhn, lddh, H, N, d, rpb);
+  else hipLaunchKernelGGL((xattn_kv_dgrad_kernel<32>), grid, block, 0, s, coef, R, (bf16*)dhn, lddh, H, N, d, rpb);
+  return check_launch("xvit_xattn_kv_dgrad");
+}
+
+extern "C" int64_t xvit_xattn_kv_wgrad_partials(int B, int H, int N, int d) {   // floats in `part`: [slices][2 H][B][d]
+  if (B <= 0 || H <= 0 || N <= 0 || d <= 0) return 0;
+  return (int64_t)B * xkv_slices(B, N, 512) * 2 * H * d;
+}
+
+extern "C" int xvit_xattn_kv_wgrad(const float* coef, const void* hn, int64_t ldh, float* part, int B, int H, int N, int d, xvit_stream_t stream) {
+  XVIT_REQUIRE(coef && hn && part, "xvit_xattn_kv_wgrad: null pointer");
+  XVIT_REQUIRE(B > 0 && B <= 65535 && N > 0 && H > 0 && 2 * H <= XKV_MAXJ && d % 4 == 0 && d <= 1024, "xvit_xattn_kv_wgrad: need 2 H <= %d, d %% 4 == 0 and d <= 1024 (B=%d H=%d N=%d d=%d)", XKV_MAXJ, B, H, N, d);
+  XVIT_REQUIRE(ldh % 4 == 0 && ldh >= d && ((uintptr_t)hn & 7) == 0 && ((uintptr_t)part & 15) == 0, "xvit_xattn_kv_wgrad: ldh must be a multiple of 4 and >= d, pointers aligned");
+  const int slices = xkv_slices(B, N, 512), rpb = (N + slices - 1) / slices;
+  const dim3 grid(slices, B), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (2 * H <= 8) hipLaunchKernelGGL((xattn_kv_wgrad_kernel<8>), grid, block, 0, s, coef, (const bf16*)hn, ldh, part, H, N, d, rpb);
+  else if (2 * H <= 16) hipLaunchKernelGGL((xattn_kv_wgrad_kernel<16>), grid, block, 0, s, coef, (const bf16*)hn, ldh, part, H, N, d, rpb);
+  else if (2 * H <= 24) hipLaunchKernelGGL((xattn_kv_wgrad_kernel<24>), grid, block, 0, s, coef, (const bf16*)hn, ldh, part, H, N, d, rpb);
+  else hipLaunchKernelGGL((xattn_kv_wgrad_kernel<32>), grid, block, 0, s, coef, (const bf16*)hn, ldh, part, H, N, d, rpb);
+  return check_launch("xvit_xattn_kv_wgrad");
 }

@@ -40,7 +40,9 @@ SIGNATURES = {
     "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_attn_fwd_fp8": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, vp, i64, vp],
     "xvit_cls_xattn_fwd": [vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
-    "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
+    "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
+    "xvit_xattn_kv_dgrad": [vp, vp, vp, i64, i32, i32, i32, i32, vp],
+    "xvit_xattn_kv_wgrad": [vp, vp, i64, vp, i32, i32, i32, i32, vp],
     "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, i32, i64, vp],
     "xvit_patch_embed_supported": [C.POINTER(PatchGeom), i32],
     "xvit_patch_embed_fwd": [vp, C.POINTER(PatchGeom), vp, i64, vp, vp, i64, vp, i64, i32, vp],
@@ -58,7 +60,7 @@ SIGNATURES = {
     "xvit_adam_step": [vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string", "xvit_gemm_workspace_bytes", "xvit_linear_f32_workspace_bytes",
-                                    "xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes", "xvit_patch_embed_wgrad_workspace_bytes", "xvit_attn_fp8_workspace_bytes"])
+                                    "xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes", "xvit_patch_embed_wgrad_workspace_bytes", "xvit_attn_fp8_workspace_bytes", "xvit_xattn_kv_wgrad_partials"])
 
 _lib = None
 
@@ -82,6 +84,8 @@ def load() -> C.CDLL:
         for name in ("xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes"):
             getattr(lib, name).argtypes = [i32, i32]
             getattr(lib, name).restype = C.c_int64
+        lib.xvit_xattn_kv_wgrad_partials.argtypes = [i32, i32, i32, i32]
+        lib.xvit_xattn_kv_wgrad_partials.restype = C.c_int64
         lib.xvit_attn_fp8_workspace_bytes.argtypes = [i32, i32, i32, i32]
         lib.xvit_attn_fp8_workspace_bytes.restype = C.c_int64
         lib.xvit_patch_embed_wgrad_workspace_bytes.argtypes = [C.POINTER(PatchGeom), i32]

@@ -287,6 +287,7 @@ def _f32c(t):
 # The all-token FFNs save gelu'(pre-activation) instead of the pre-activation itself (xvit_gemm aux_mode 1): the forward epilogue
 # has the exponential at hand anyway, and the GELU' dgrad epilogue becomes a multiply.  XVIT_GELU_AUX=z restores the old form.
 AUX_MODE = 0 if os.environ.get("XVIT_GELU_AUX", "deriv") == "z" else 1
+XATTN_LOWRANK = os.environ.get("XVIT_XATTN_LOWRANK", "1") == "1"
 
 
 def _attn_fwd(qkv, B, N, H, scale, p=0.0, seed=0):
@@ -455,15 +456,23 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
         ops.colsum(dyb1, out=g["bp"], accumulate=True)
     doc = _dgrad(dyb1, wp_s)
     g["wp"] = _wgrad(dyb1, oc)
-    dq, dkv = ops.cls_xattn_bwd(q, kv, p, doc, B, N, H, scale, dropout=(pd, seeds[0]))
+    # dK / dV of one (b, head) are rank one (a coefficient per key times q_h resp. dO_h): with 2 H <= 32 the K/V projection's
+    # backward runs in that form — no [B N, 2 d] gradient tensor, no K = 2 d dgrad / wgrad GEMMs, no column-sum pass over it
+    # (XVIT_XATTN_LOWRANK=0: the dense form)
+    low_rank = XATTN_LOWRANK and 2 * H <= 32 and d == 64 * H and d <= 1024
+    dq, dkv = ops.cls_xattn_bwd(q, kv, p, doc, B, N, H, scale, dropout=(pd, seeds[0]), low_rank=low_rank)
     dqb = ops.cast_bf16(dq)
-    dhn = _dgrad(dkv, wkv_s)                                # [B*N, d] bf16
+    if low_rank:
+        dhn, g["wkv"], g["bkv"] = ops.xattn_kv_backward(dkv, q, doc, wkv_s, hn, B, N, H)
+    else:
+        dhn = _dgrad(dkv, wkv_s)                            # [B*N, d] bf16
     dhq = _dgrad(dqb, wq_s)                                 # [B, d] bf16: the query path reaches row 0 only
     dhn0 = dhn.reshape(B, N * d)[:, :d]
     dhn0.copy_(dhn0.float() + dhq.float())                  # B rows: merge the two paths into the CLS rows
     hn0 = hn.reshape(B, N * d)[:, :d]
-    g["wkv"] = _wgrad(dkv, hn)
-    g["bkv"] = ops.colsum(dkv)
+    if not low_rank:
+        g["wkv"] = _wgrad(dkv, hn)
+        g["bkv"] = ops.colsum(dkv)
     g["wq"] = _wgrad(dqb, hn0)
     g["bq"] = ops.colsum(dq)
     dcat, _ = ops.layernorm_bwd(dhn, xj, mu, rs, ln1w, g["ln1w"], g["ln1b"], x_alt=xi, seq_len=N)

@@ -291,19 +291,49 @@ def cls_xattn_fwd(q, kv, B, N, H, scale, dropout=(0.0, 0), want_f32=False):
     return (o, p, of) if want_f32 else (o, p)
 
 
-def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale, dropout=(0.0, 0)):
-    """-> (dq fp32 [B, d], dkv bf16 [B*N, 2d])."""
+def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale, dropout=(0.0, 0), low_rank=False):
+    """-> (dq fp32 [B, d], dkv bf16 [B*N, 2d])   or, low_rank: (dq, coef fp32 [B, N, 2H]) with dk[n] = coef[.., h] q_h and
+    dv[n] = coef[.., H + h] dO_h (include/xvit.h): the input of xattn_kv_dgrad / xattn_kv_wgrad."""
     d = q.shape[1]
     dq = torch.empty(B, d, dtype=torch.float32, device=q.device)
-    dkv = torch.empty_like(kv)
     ld = _rows2d(kv)
-    assert dkv.stride(0) == ld
-    kp, gp = kv.data_ptr(), dkv.data_ptr()
-    _run("cls_xattn_bwd", B * N * 2.0 * d * 2 * 2, "byte",
+    kp = kv.data_ptr()
+    if low_rank:
+        out = torch.empty(B, N, 2 * H, dtype=torch.float32, device=q.device)
+        gk = gv = None
+        work = B * N * 2.0 * d * 2
+    else:
+        out = torch.empty_like(kv)
+        assert out.stride(0) == ld
+        gk, gv = out.data_ptr(), out.data_ptr() + 2 * d
+        work = B * N * 2.0 * d * 2 * 2
+    _run("cls_xattn_bwd", work, "byte",
          lambda: _lib.load().xvit_cls_xattn_bwd(_ptr(q), _rows2d(q), kp, kp + 2 * d, N * ld, ld, _ptr(p), _ptr(d_o), _rows2d(d_o), _ptr(dq), d,
-                                                gp, gp + 2 * d, B, H, N, d // H, scale, float(dropout[0]), int(dropout[1]), _stream()),
+                                                gk, gv, _ptr(out) if low_rank else None, B, H, N, d // H, scale, float(dropout[0]), int(dropout[1]), _stream()),
          "xvit_cls_xattn_bwd")
-    return dq, dkv
+    return dq, out
+
+
+def xattn_kv_backward(coef, q, d_o, wkv_b, hn, B, N, H):
+    """Low-rank backward of the fusion's K/V projection (kv = hn Wkv^T + bkv, model_cross.py:92-93) from the coefficients of
+    cls_xattn_bwd(low_rank=True): -> (dhn bf16 [B*N, d], dWkv fp32 [2d, d], dbkv fp32 [2d]).  q, d_o: bf16 [B, d] (the CLS query and
+    the gradient of the attention output); wkv_b: bf16 [2d, d]; hn: bf16 [B*N, d] (the normed tokens)."""
+    d = q.shape[1]
+    lib = _lib.load()
+    vec = torch.cat((q.view(B, H, d // H), d_o.view(B, H, d // H)), dim=1).float()      # [B, 2H, 64]: q_h, then dO_h
+    wf = wkv_b.float().view(2 * H, d // H, d)                                           # (wk | wv)[head][e][:]
+    R = torch.bmm(vec.transpose(0, 1), wf)                                              # [2H, B, d]: R[h] = q_h Wk_h, R[H + h] = dO_h Wv_h
+    dhn = torch.empty(B * N, d, dtype=torch.bfloat16, device=q.device)
+    _run("xattn_kv_dgrad", B * N * d * 2.0 + B * N * 2 * H * 4.0, "byte",
+         lambda: lib.xvit_xattn_kv_dgrad(_ptr(coef), _ptr(R), _ptr(dhn), d, B, H, N, d, _stream()), "xvit_xattn_kv_dgrad")
+    nfl = lib.xvit_xattn_kv_wgrad_partials(B, H, N, d)
+    part = torch.empty(nfl, dtype=torch.float32, device=q.device)
+    _run("xattn_kv_wgrad", B * N * d * 2.0 + B * N * 2 * H * 4.0, "byte",
+         lambda: lib.xvit_xattn_kv_wgrad(_ptr(coef), _ptr(hn), _rows2d(hn), _ptr(part), B, H, N, d, _stream()), "xvit_xattn_kv_wgrad")
+    T = part.view(-1, 2 * H, B, d).sum(0)                                               # [2H, B, d]: the row slices, in a fixed order
+    dW = torch.bmm(vec.permute(1, 2, 0), T).reshape(2 * d, d)                           # dWk[64 h + e, :] = sum_b q[b, h, e] T[h, b, :]; dWv likewise
+    db = (vec * coef.sum(1)[:, :, None]).sum(0).reshape(2 * d)                          # bias: the coefficients summed over the tokens
+    return dhn, dW, db
 
 
 def patchify(img, patch, pad_cls_row=False, concat=False):

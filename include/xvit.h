@@ -166,8 +166,19 @@ int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const float* q_f32, int64_t l
                        float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
 /* dropout_p / dropout_seed: attn_drop on the probabilities (model_cross.py:97); p[] holds the pre-dropout values */
 int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v, int64_t stride_b, int64_t stride_n, const float* p,
-                       const void* d_o, int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, int B, int H, int N, int dh,
+                       const void* d_o, int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, float* coef, int B, int H, int N, int dh,
                        float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
+/* dk / dv (bf16, laid out like k / v; both or neither) and / or coef (fp32 [B, N, 2 H]).  dK and dV of one (b, head) are rank one:
+ * dk[n] = coef[b][n][head] * q_head (the softmax scale included), dv[n] = coef[b][n][H + head] * dO_head.  With coef the gradient
+ * of the K/V projection (model_cross.py:92-93: wk, wv over all N tokens) is taken in that low-rank form, without the [B N, 2 d] tensor:
+ *   xvit_xattn_kv_dgrad: dhn[b, n, :] (bf16) = dk[b, n, :] Wk + dv[b, n, :] Wv = sum_j coef[b, n, j] R[j, b, :], with R (fp32 [2 H, B, d])
+ *     R[h, b, :] = q[b, h, :] Wk[64 h .. 64 h + 63, :], R[H + h, b, :] = dO[b, h, :] Wv[64 h .., :] supplied by the caller (one batched product);
+ *   xvit_xattn_kv_wgrad: part[slice][j][b][:] (fp32) = sum over the slice's rows n of coef[b, n, j] hn[b, n, :]; summed over the slices
+ *     (fixed order) this is T[j, b, :], and dWk[64 h + e, :] = sum_b q[b, h, e] T[h, b, :], dWv likewise with dO and T[H + h, b, :].
+ *   xvit_xattn_kv_wgrad_partials: number of floats `part` must hold.  d = 64 H, 2 H <= 32. */
+int xvit_xattn_kv_dgrad(const float* coef, const float* R, void* dhn_bf16, int64_t lddh, int B, int H, int N, int d, xvit_stream_t stream);
+int64_t xvit_xattn_kv_wgrad_partials(int B, int H, int N, int d);
+int xvit_xattn_kv_wgrad(const float* coef, const void* hn_bf16, int64_t ldh, float* part, int B, int H, int N, int d, xvit_stream_t stream);
 
 /* MX-fp8 forward attention (BASELINE.json configs[4] "fp8 MFMA QK^T/AV path"; reference ops model_cross.py:55-59):
  * same arguments and outputs as xvit_attn_fwd without dropout, but q, k, v are first quantised to OCP e4m3 with one e8m0

@@ -231,3 +231,32 @@ def test_input_stage_resize_pad_crop_int16(src, dst):
     out = ops.resize_pad_crop_i16(vol.to(dev()), dst, -1.0)
     ref = R.resize_with_pad_or_crop(vol, dst, -1.0).to(torch.bfloat16).reshape(2, 2, 1, *dst)
     assert out.shape == ref.shape and torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("B,N,H", [(3, 17, 3), (5, 513, 12), (2, 130, 4), (1, 1000, 16)])
+def test_xattn_kv_backward_low_rank(B, N, H):
+    """The fusion's K/V projection backward in its low-rank form (xvit_xattn_kv_dgrad / _wgrad from the coefficients of
+    xvit_cls_xattn_bwd, reference model_cross.py:92-99) against the dense chain dkv -> dkv Wkv, dkv^T hn, colsum(dkv) in fp64."""
+    ops = _ops()
+    d = 64 * H
+    scale = 0.125
+    qv, kv = rt(randn(B, d, seed=1)), rt(randn(B, N, 2 * d, seed=2))
+    do = rt(randn(B, d, seed=3))
+    wkv = rt(randn(2 * d, d, seed=4, scale=d ** -0.5))
+    hn = rt(randn(B * N, d, seed=5))
+    gq, gkv = qv.to(dev(), torch.bfloat16), kv.to(dev(), torch.bfloat16).reshape(B * N, 2 * d)
+    p = ops.cls_xattn_fwd(gq, gkv, B, N, H, scale)[1]
+    dq1, dkv = ops.cls_xattn_bwd(gq, gkv, p, do.to(dev(), torch.bfloat16), B, N, H, scale)
+    dq2, coef = ops.cls_xattn_bwd(gq, gkv, p, do.to(dev(), torch.bfloat16), B, N, H, scale, low_rank=True)
+    assert torch.equal(dq1, dq2)
+    # the coefficients reproduce the dense dk / dv (which are their bf16 roundings)
+    c = coef.double().cpu()
+    dk = (c[:, :, :H, None] * qv.double().view(B, 1, H, 64)).reshape(B * N, d)
+    dv = (c[:, :, H:, None] * do.double().view(B, 1, H, 64)).reshape(B * N, d)
+    dense = torch.cat((dk, dv), dim=1)
+    assert_close(dkv, dense.float(), "dkv from the coefficients")
+    dhn, dW, db = ops.xattn_kv_backward(coef, gq, do.to(dev(), torch.bfloat16), wkv.to(dev(), torch.bfloat16), hn.to(dev(), torch.bfloat16), B, N, H)
+    assert_close(dhn, (dense @ wkv.double()).float(), "dhn = dkv Wkv")
+    assert rel(dW, (dense.T @ hn.double()).float()) < 1e-5, rel(dW, (dense.T @ hn.double()).float())
+    ref_db = dense.sum(0).float()
+    assert float((db.cpu() - ref_db).abs().max()) < 1e-4 * max(1.0, float(ref_db.abs().max()))
