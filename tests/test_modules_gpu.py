@@ -428,3 +428,27 @@ def test_inplace_cls_splice_equals_copying_form(monkeypatch):
     assert torch.equal(res["1"][0], res["0"][0])
     for k in res["1"][1]:
         assert torch.equal(res["1"][1][k], res["0"][1][k]), k
+
+
+def test_fusion_kv_backward_low_rank_vs_dense(monkeypatch):
+    """The fusion's K/V projection backward: low-rank kernels (default) against the dense chain (dkv tensor, two GEMMs, column sums;
+    used when 2 H > 32 or d > 1024).  Same logits; gradients agree to the bf16 rounding of dkv that only the dense chain has."""
+    import xvit
+    import xvit.functional as XF
+    cfg = R.make_config("small")
+    sd = R.make_state_dict(cfg, seed=6)
+    img, labels = R.make_inputs(cfg, 3, seed=6)
+    res = {}
+    for low in (True, False):
+        monkeypatch.setattr(XF, "XATTN_LOWRANK", low)
+        model = xvit.ModelCross(cfg).to(dev())
+        model.load_state_dict(sd)
+        model.train()
+        logits, loss = model(img.to(dev()), labels.to(dev()))
+        loss.backward()
+        res[low] = (logits.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    assert torch.equal(res[True][0], res[False][0])
+    for k, g in res[True][1].items():
+        if k.endswith("wk.bias"):
+            continue                      # analytically zero (softmax gradients sum to zero over the keys): rounding noise in both forms
+        assert rel(g, res[False][1][k]) < 2e-2 or float(res[False][1][k].abs().max()) < 1e-6, (k, rel(g, res[False][1][k]))
