@@ -12,7 +12,13 @@
 // conflict-free.  v_mfma_f32_32x32x16_bf16 throughout.  No [N,N] tensor ever reaches HBM; the
 // backward recomputes P from the saved log-sum-exp.  dQ and dK/dV are separate kernels, so no
 // atomics and bit-reproducible gradients.
+#include <atomic>
+
 #include "xvit_common.h"
+
+#ifndef XVIT_PEEL_DEBUG
+#define XVIT_PEEL_DEBUG 0     // timing-only diagnostic builds (WRONG results): 1 = no post-loop token-0 block, 2 = no token-0 initial state, 4 = no tile rotation
+#endif
 
 namespace xvit {
 
@@ -145,6 +151,30 @@ __device__ __forceinline__ void ring_wait(int t, int ntiles) {
   else if (NST >= 3 && ahead >= 1) wait_vmcnt<PT>();
   else wait_vmcnt<0>();
 }
+// PEEL: workgroup x of a (b, head) walks the streamed tiles in ROTATED order, ending with the two tiles (2x, 2x+1) that hold the
+// tokens with its own row indices.  Softmax statistics and the gradient sums do not depend on the order, and after the loop
+// those two tiles are still in the ring, so each wave runs its one token-0 block (see "CLS peel" below) THERE: all four waves
+// at once, behind the last barrier.  (Inside the loop the extra block of one wave held the other three at the next
+// barrier: +15..20 % per kernel measured instead of the +6 % of work.)
+struct TileOrder {
+  int own, pair, ntiles;   // own = first tile of the workgroup's pair, pair = 1 or 2 tiles (0: natural order)
+  __device__ __forceinline__ void init(bool peel, int x, int nt) {
+    ntiles = nt;
+    own = 2 * x;
+    pair = (peel && !(XVIT_PEEL_DEBUG & 4)) ? min(2, nt - own) : 0;
+  }
+  // every other tile in natural order (the workgroups of a (b, head) keep streaming the same tiles at about the same time: L2), then the own pair
+  __device__ __forceinline__ int tile(int it) const {
+    if (pair == 0) return it;
+    const int head = ntiles - pair;
+    return it >= head ? own + (it - head) : (it < own ? it : it + pair);
+  }
+  // ring stage that still holds token-0 block `g`'s tile after the loop (g = 4 x + wave; its tile is 2x or 2x + 1)
+  __device__ __forceinline__ int stage_of(int g, int nst) const {
+    const int it = pair == 0 ? (g >> 1) : ntiles - pair + ((g >> 1) - own);
+    return it % nst;
+  }
+};
 #ifndef XVIT_BWD_NST
 #define XVIT_BWD_NST 2
 #endif
@@ -172,6 +202,75 @@ __device__ __forceinline__ void store_lane_rows(const f32x16 (&acc)[2], float mu
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// CLS peel (N = 64 m + 1: the reference's cls token + a whole number of patch-token tiles, model_cross.py:195-196).
+// Token 0 would cost a whole extra query block per (b, head) and a whole extra key tile per block (5 x 9 block-tiles
+// instead of 4 x 8 at N = 513: +47 % forward, +23 % backward measured) for one row and one column of work.  With
+// PEEL the tile grid covers the patch tokens 1 .. N-1 only and token 0 rides along as rank-one side work:
+//   * CLS as a KEY is one column of S: per query (lane) one 64-long dot gives its score, so it enters the forward as the
+//     INITIAL online-softmax state (m = s0, l = 1, O = v0) and the backward's dQ kernel as the initial accumulator
+//     dQ = dS[q, 0] k0; its own gradients dK0 = sum_q dS[q, 0] Q[q], dV0 = sum_q P[q, 0] dO[q] are column sums over queries:
+//     the dK/dV kernel (Q / dO tiles in LDS) takes them as ONE extra MFMA block per wave whose key operand is k0 / v0
+//     repeated in all 32 columns.
+//   * CLS as a QUERY is one row of S: the dK/dV kernel (key on the lane) adds its rank-one terms dK[k] += dS[0, k] q0,
+//     dV[k] += P[0, k] dO0 as the initial accumulators; its own output O[0] (forward) and gradient dQ0 (backward) are row sums
+//     over keys: the forward / dQ kernels (K / V tiles in LDS) take them as ONE extra MFMA block per wave whose query
+//     operand is q0 / dO0 repeated in all 32 columns, each wave over the 32 keys whose index equals its own query block.
+// Every wave leaves its partial (fixed slot), a small merge kernel adds them in slot order and finishes row 0: no atomics,
+// bit-reproducible.  The extra block is 1/16 of a wave's work at N = 513 and 1/128 at N = 4097.
+// ------------------------------------------------------------------------------------------
+constexpr int CLS_SLOT = 80;   // floats per forward partial: o[64] (unnormalised) | m (raw max) | l | pad (16-B aligned rows)
+
+// row `rowp` (64 bf16) as an MFMA operand whose 32 columns (B) / rows (A) all equal that row
+__device__ __forceinline__ void load_row_bcast(bf16x8 (&f)[4], const bf16* rowp, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f[ks] = *(const bf16x8*)(rowp + ks * 16 + h * 8);
+}
+// the same row as fp32 in accumulator order: x[db][i] = row[32 db + acc_row(i, h)]
+__device__ __forceinline__ void load_row_acc(f32x16 (&x)[2], const bf16* rowp, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const bf16x4 t = *(const bf16x4*)(rowp + 32 * db + 8 * g + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[db][4 * g + e] = bf2f(t[e]);
+    }
+}
+// Token-0 rows for the post-loop block, prefetched into LDS: one LDS-DMA per row, issued by wave 0 BEFORE its first tile DMAs (so its
+// first ring wait covers them, and the loop's first barrier publishes them); the row is repeated over the instruction's 1 KiB
+// (lane L fetches 16-byte chunk L & 7).  A global load after the loop would expose ~1-2 us of latency per workgroup (measured:
+// 12 us of a 170 us forward, 33 us of a 540 us backward at B = 126, N = 513).
+constexpr int ROW0_BYTES = 1024;
+__device__ __forceinline__ void stage_row0(XVIT_LDS char* dst, const bf16* rowp, int lane) {
+  glds16(make_rsrc(rowp, 128), dst, (uint32_t)((lane & 7) * 16), 0);
+}
+__device__ __forceinline__ void lds_row_bcast(bf16x8 (&f)[4], const XVIT_LDS char* row, int lane) {
+  const int h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) f[ks] = *(const XVIT_LDS bf16x8*)(row + ks * 32 + h * 16);
+}
+// dot over d of two operand fragment sets: each lane holds 32 of the 64 d, the lane halves complete each other
+__device__ __forceinline__ float frag_dot(const bf16x8 (&a)[4], const bf16x8 (&b)[4]) {
+  float p = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p = fmaf(bf2f(a[ks][j]), bf2f(b[ks][j]), p);
+  return half_sum(p);
+}
+// column 0 of a [64 d][32 identical columns] accumulator pair -> 64 consecutive floats
+__device__ __forceinline__ void store_col0(const f32x16 (&acc)[2], float* dst, int lane) {
+  if ((lane & 31) != 0) return;
+  const int h = lane >> 5;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *(f32x4*)(dst + 32 * db + 8 * g + 4 * h) = f32x4{acc[db][4 * g], acc[db][4 * g + 1], acc[db][4 * g + 2], acc[db][4 * g + 3]};
+}
+
 // Probability dropout (reference model.py:169: attention_probs = attn_dropout(softmax(scores))): element (b, h, query, key) is
 // kept iff hash32(seed, ((b H + h) N + query) N + key) >= p 2^24 — the mask xvit_dropout applies to a contiguous [B, H, N, N]
 // tensor with the same seed — and scaled by 1/(1-p).  The row sums (softmax normaliser) use the probabilities BEFORE the
@@ -196,10 +295,11 @@ constexpr int FWD_KS = 2, FWD_SS = 1;
 constexpr int FWD_KS = 4, FWD_SS = 2;
 #endif
 
-template <int QB, bool DROP>
+template <int QB, bool DROP, bool PEEL>
 __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                           int64_t sb, int64_t sn, bf16* __restrict__ o, int64_t osb, int64_t osn,
-                                                          float* __restrict__ lse, int H, int N, float scale, const DropArgs drop) {
+                                                          float* __restrict__ lse, int H, int N, float scale, const DropArgs drop, float* __restrict__ cls_ws) {
+  static_assert(!PEEL || (QB == 1 && !DROP), "the CLS peel is built for 32 queries per wave, no probability dropout");
 #ifdef XVIT_DEBUG_ATTN_TIMES
   const uint64_t wc_entry = wall_clock64();
 #endif
@@ -209,26 +309,34 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
   const BlockCoord bc = xcd_block_coord();
   const int b = bc.b, head = bc.head;
   const int q0 = bc.x * (128 * QB) + wave * (32 * QB);
-  const int64_t off = (int64_t)b * sb + head * DH;
-  const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+  const int NK = PEEL ? N - 1 : N;                                   // tokens of the tile grid (PEEL: the patch tokens, rows 1 .. N-1)
+  const int64_t off0 = (int64_t)b * sb + head * DH;                  // token 0 of this (b, head)
+  const int64_t off = off0 + (PEEL ? sn : 0);                        // first token of the tile grid
+  const int ntiles = (NK + TILE_ROWS - 1) / TILE_ROWS;
 
   // K/V tiles stream through a FWD_NST-deep LDS ring.  Loads stay in flight ACROSS iterations: each wave
   // issues exactly 4 LDS-DMA instructions per tile (2 K + 2 V), so "tile t has landed, tile t+1 may still be
   // in flight" is a counted s_waitcnt vmcnt(4); barriers are raw s_barrier (a __syncthreads() would drain
   // vmcnt to 0 and serialise every iteration behind a full HBM/L2 round trip).
   TileLoader lk, lv;
-  lk.init(k + off, sn, N, wave, lane);
-  lv.init(v + off, sn, N, wave, lane);
+  lk.init(k + off, sn, NK, wave, lane);
+  lv.init(v + off, sn, NK, wave, lane);
+  TileOrder ord;
+  ord.init(PEEL, bc.x, ntiles);
+  XVIT_LDS char* row0 = smem + FWD_NST * 2 * IMG_BYTES;   // PEEL: [q0] (ROW0_BYTES)
+  if constexpr (PEEL) {
+    if (wave == 0) stage_row0(row0, q + off0, lane);
+  }
 #pragma unroll
   for (int st = 0; st < FWD_NST - 1; ++st)
     if (st < ntiles) {
-      lk.issue(smem + st * 2 * IMG_BYTES, wave, st);
-      lv.issue(smem + st * 2 * IMG_BYTES + IMG_BYTES, wave, st);
+      lk.issue(smem + st * 2 * IMG_BYTES, wave, ord.tile(st));
+      lv.issue(smem + st * 2 * IMG_BYTES + IMG_BYTES, wave, ord.tile(st));
     }
   bf16x8 qf[QB][4];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    load_lane_operand(qf[qb], q + off, sn, q0 + qb * 32, N, lane);   // one round trip together with the first ring tiles
+    load_lane_operand(qf[qb], q + off, sn, q0 + qb * 32, NK, lane);   // one round trip together with the first ring tiles
     settle(qf[qb]);                                                  // (drains the prologue's DMAs too: fine, they are needed first)
   }
   ImgReader rd;
@@ -236,7 +344,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
 
   const int h = lane >> 5;
   const float c = scale * LOG2E;
-  const bool wave_active = q0 < N;   // wave-uniform
+  const bool wave_active = q0 < NK;   // wave-uniform
   float m_run[QB], l_run[QB];
   f32x16 oacc[QB][2];
 #pragma unroll
@@ -244,6 +352,17 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
     m_run[qb] = -INFINITY; l_run[qb] = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { oacc[qb][0][i] = 0.f; oacc[qb][1][i] = 0.f; }
+  }
+  // PEEL: the CLS key is the initial online-softmax state of every query: m = s0 = q . k0 (raw, like the MFMA scores), p0 = 1, O = v0.
+  // (l_run is a per-lane-half partial sum: the 1 goes to half 0.)  This wave's CLS-QUERY block: the 32 keys with its own queries' indices.
+  const int cls_g = bc.x * 4 + wave, cls_kb = cls_g & 1;
+  if constexpr (PEEL && !(XVIT_PEEL_DEBUG & 2)) {
+    bf16x8 k0f[4];
+    load_row_bcast(k0f, k + off0, lane);
+    m_run[0] = frag_dot(qf[0], k0f);
+    l_run[0] = h == 0 ? 1.f : 0.f;
+    load_row_acc(oacc[0], v + off0, lane);
+    asm volatile("" : "+v"(m_run[0]));   // settle these loads before the tile loop: see settle()
   }
 
 #ifdef XVIT_DEBUG_ATTN_TIMES
@@ -262,8 +381,8 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
     if (t + FWD_NST - 1 < ntiles) {
       int ns = stage + FWD_NST - 1;
       if (ns >= FWD_NST) ns -= FWD_NST;
-      lk.issue(smem + ns * 2 * IMG_BYTES, wave, t + FWD_NST - 1);
-      lv.issue(smem + ns * 2 * IMG_BYTES + IMG_BYTES, wave, t + FWD_NST - 1);
+      lk.issue(smem + ns * 2 * IMG_BYTES, wave, ord.tile(t + FWD_NST - 1));
+      lv.issue(smem + ns * 2 * IMG_BYTES + IMG_BYTES, wave, ord.tile(t + FWD_NST - 1));
     }
     const XVIT_LDS char* kimg = smem + stage * 2 * IMG_BYTES;
     const XVIT_LDS char* vimg = kimg + IMG_BYTES;
@@ -271,7 +390,7 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
 
     if (!wave_active) continue;   // this wave's queries are all past N: keep moving tiles and barriers, skip the math
     // keys of this tile past N: with <= 32 valid keys the second 32-key block is skipped entirely
-    const int valid = N - t * TILE_ROWS;
+    const int valid = PEEL ? TILE_ROWS : NK - t * TILE_ROWS;   // PEEL: 64 | NK, every tile is full
     const bool two = valid > 32;
 
     // S^T[key][query] = K Q^T: every K fragment is read once and used by all QB query blocks
@@ -396,9 +515,38 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
   for (int qb = 0; qb < QB; ++qb) {
     const float l_tot = half_sum(l_run[qb]);
     const int qrow = q0 + qb * 32 + (lane & 31);
-    const bool valid = qrow < N;
-    if (valid && h == 0) lse[((int64_t)b * H + head) * N + qrow] = m_run[qb] * scale + __logf(l_tot);
-    store_lane_rows(oacc[qb], 1.0f / l_tot, o + (int64_t)b * osb + head * DH, osn, qrow, valid, lane);
+    const bool valid = qrow < NK;
+    if (valid && h == 0) lse[((int64_t)b * H + head) * N + (PEEL ? 1 : 0) + qrow] = m_run[qb] * scale + __logf(l_tot);
+    store_lane_rows(oacc[qb], 1.0f / l_tot, o + (int64_t)b * osb + head * DH + (PEEL ? osn : 0), osn, qrow, valid, lane);
+  }
+  if constexpr (PEEL && !(XVIT_PEEL_DEBUG & 1)) {
+    if (wave_active) {   // once per wave, after the loop: the CLS query against key block cls_kb of its own tile (still in the ring), q0 in all 32 columns
+      const XVIT_LDS char* kimg = smem + ord.stage_of(cls_g, FWD_NST) * 2 * IMG_BYTES;
+      const XVIT_LDS char* vimg = kimg + IMG_BYTES;
+      bf16x8 q0f[4];
+      lds_row_bcast(q0f, row0, lane);
+      f32x16 sc;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, cls_kb, ks), q0f[ks], ks == 0 ? ZERO16 : sc, 0, 0, 0);
+      float mx = sc[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sc[i]);
+      mx = half_max(mx);
+      float ps = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sc[i] = __builtin_amdgcn_exp2f((sc[i] - mx) * c); ps += sc[i]; }
+      ps = half_sum(ps);
+      f32x16 oc[2];
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const bf16x8 pf = acc_frag(sc, ss);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) oc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(vimg, db, cls_kb, ss), pf, ss == 0 ? ZERO16 : oc[db], 0, 0, 0);
+      }
+      float* slot = cls_ws + ((((int64_t)b * H + head) * (NK / 32)) + cls_g) * CLS_SLOT;
+      store_col0(oc, slot, lane);
+      if (lane == 0) { slot[64] = mx; slot[65] = ps; }
+    }
   }
 }
 
@@ -406,42 +554,81 @@ __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf
 // backward, dQ: one wave = 32 queries, streams K and V tiles
 // ------------------------------------------------------------------------------------------
 // (133 VGPRs: three blocks per CU; squeezing it to 128 for a fourth spills and measured 6 % slower)
-template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
+// one 32-key block of the dQ recomputation: S^T = K Q^T, dP^T = V dO^T -> dS^T = P^T (dP^T - delta) -> dQ^T += K^T dS^T.  qf / dof: the
+// queries on the lanes (or, for the CLS row, q0 / dO0 repeated in every column); nlse / dlt: their row statistics
+__device__ __forceinline__ void dq_block(const ImgReader& rd, const XVIT_LDS char* kimg, const XVIT_LDS char* vimg, int kb, const bf16x8 (&qf)[4],
+                                         const bf16x8 (&dof)[4], float c, float nlse, float dlt, f32x16 (&dqacc)[2]) {
+  f32x16 s, dp;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(kimg, kb, ks), qf[ks], ks == 0 ? ZERO16 : s, 0, 0, 0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(vimg, kb, ks), dof[ks], ks == 0 ? ZERO16 : dp, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s[i] = __builtin_amdgcn_exp2f(fmaf(s[i], c, nlse)) * (dp[i] - dlt);
+#pragma unroll
+  for (int ss = 0; ss < 2; ++ss) {
+    const bf16x8 dsf = acc_frag(s, ss);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) dqacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(kimg, db, kb, ss), dsf, dqacc[db], 0, 0, 0);
+  }
+}
+
+// PEEL workspace (after delta | nlse): per (b, head) and wave slot g, 64 floats each of dQ0, dK0, dV0 partials
+#ifndef XVIT_DQ_PEEL_WAVES
+#define XVIT_DQ_PEEL_WAVES 4
+#endif
+#ifndef XVIT_DKV_PEEL_WAVES
+#define XVIT_DKV_PEEL_WAVES 3
+#endif
+template <bool DROP, bool PEEL>
+__global__ __launch_bounds__(256, PEEL ? XVIT_DQ_PEEL_WAVES : 2) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                              int64_t sb, int64_t sn, const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb,
                                                              int64_t osn, const float* __restrict__ lse, float* __restrict__ nlse_ws,
-                                                             float* __restrict__ delta, bf16* __restrict__ dq, int H, int N, float scale, const DropArgs drop) {
+                                                             float* __restrict__ delta, bf16* __restrict__ dq, int H, int N, float scale, const DropArgs drop,
+                                                             float* __restrict__ pdq) {
+  static_assert(!PEEL || !DROP, "the CLS peel is built without probability dropout");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const BlockCoord bc = xcd_block_coord();
   const int b = bc.b, head = bc.head;
   const int q0 = bc.x * 128 + wave * 32;
-  const int64_t off = (int64_t)b * sb + head * DH;
-  const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+  const int NK = PEEL ? N - 1 : N;
+  const int64_t off0 = (int64_t)b * sb + head * DH, off = off0 + (PEEL ? sn : 0);
+  const int64_t ooff0 = (int64_t)b * osb + head * DH, ooff = ooff0 + (PEEL ? osn : 0);
+  const int ntiles = (NK + TILE_ROWS - 1) / TILE_ROWS;
 
   TileLoader lk, lv;
-  lk.init(k + off, sn, N, wave, lane);
-  lv.init(v + off, sn, N, wave, lane);
+  lk.init(k + off, sn, NK, wave, lane);
+  lv.init(v + off, sn, NK, wave, lane);
+  TileOrder ord;
+  ord.init(PEEL, bc.x, ntiles);
+  XVIT_LDS char* row0 = smem + BWD_NST * 2 * IMG_BYTES;   // PEEL: [q0 | dO0] (2 ROW0_BYTES)
+  if constexpr (PEEL) {
+    if (wave == 0) {
+      stage_row0(row0, q + off0, lane);
+      stage_row0(row0 + ROW0_BYTES, d_o + ooff0, lane);
+    }
+  }
 #pragma unroll
   for (int st = 0; st < BWD_NST - 1; ++st)
     if (st < ntiles) {
-      lk.issue(smem + st * 2 * IMG_BYTES, wave, st);
-      lv.issue(smem + st * 2 * IMG_BYTES + IMG_BYTES, wave, st);
+      lk.issue(smem + st * 2 * IMG_BYTES, wave, ord.tile(st));
+      lv.issue(smem + st * 2 * IMG_BYTES + IMG_BYTES, wave, ord.tile(st));
     }
 
   bf16x8 qf[4], dof[4];
-  load_lane_operand(qf, q + off, sn, q0, N, lane);
-  load_lane_operand(dof, d_o + (int64_t)b * osb + head * DH, osn, q0, N, lane);
+  load_lane_operand(qf, q + off, sn, q0, NK, lane);
+  load_lane_operand(dof, d_o + ooff, osn, q0, NK, lane);
   settle(qf);
   settle(dof);
   ImgReader rd;
   rd.init(lane);
 
   const int qrow = q0 + (lane & 31);
-  const bool valid = qrow < N;
-  const bool wave_active = q0 < N;   // wave-uniform
-  const int64_t stat = ((int64_t)b * H + head) * N + qrow;
+  const bool valid = qrow < NK;
+  const bool wave_active = q0 < NK;   // wave-uniform
+  const int64_t stat = ((int64_t)b * H + head) * N + (PEEL ? 1 : 0) + qrow;
   const float c = scale * LOG2E;
   // Row statistics of the backward, computed HERE from the query rows this wave already holds (dO in registers, O loaded the
   // same way) and left in the workspace for the dK/dV kernel, which is launched after this one: delta = rowsum(dO . O) and
@@ -450,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   float nlse, dlt;
   {
     bf16x8 of[4];
-    load_lane_operand(of, o + (int64_t)b * osb + head * DH, osn, q0, N, lane);
+    load_lane_operand(of, o + ooff, osn, q0, NK, lane);
     float part = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
@@ -465,6 +652,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
   f32x16 dqacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dqacc[0][i] = 0.f; dqacc[1][i] = 0.f; }
+  // PEEL: the CLS key's column of dS is one scalar per query (lane): dS[q, 0] = P[q, 0] (dO[q] . v0 - delta[q]), and its term of
+  // dQ[q] = sum_k dS[q, k] K[k] is the initial accumulator dS[q, 0] k0.  This wave's CLS-QUERY block: the keys with its own indices.
+  const int cls_g = bc.x * 4 + wave, cls_kb = cls_g & 1;
+  float nlse0 = 0.f, dlt0 = 0.f;   // the CLS query's row statistics (post-loop block)
+  if constexpr (PEEL) {
+    bf16x8 do0f[4], o0f[4];
+    load_row_bcast(do0f, d_o + ooff0, lane);
+    load_row_bcast(o0f, o + ooff0, lane);
+    nlse0 = -lse[((int64_t)b * H + head) * N] * LOG2E;
+    dlt0 = frag_dot(o0f, do0f);
+  }
+  if constexpr (PEEL && !(XVIT_PEEL_DEBUG & 2)) {
+    bf16x8 k0f[4], v0f[4];
+    load_row_bcast(k0f, k + off0, lane);
+    load_row_bcast(v0f, v + off0, lane);
+    const float p0 = __builtin_amdgcn_exp2f(fmaf(frag_dot(qf, k0f), c, nlse));
+    float ds0 = p0 * (frag_dot(dof, v0f) - dlt);
+    f32x16 k0a[2];
+    load_row_acc(k0a, k + off0, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dqacc[0][i] = ds0 * k0a[0][i]; dqacc[1][i] = ds0 * k0a[1][i]; }
+    asm volatile("" : "+v"(ds0));   // settle these loads before the tile loop: see settle()
+  }
+  asm volatile("" : "+v"(nlse0), "+v"(dlt0));
 
   int stage = 0;
   for (int t = 0; t < ntiles; ++t) {
@@ -473,14 +684,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
     if (t + BWD_NST - 1 < ntiles) {
       int ns = stage + BWD_NST - 1;
       if (ns >= BWD_NST) ns -= BWD_NST;
-      lk.issue(smem + ns * 2 * IMG_BYTES, wave, t + BWD_NST - 1);
-      lv.issue(smem + ns * 2 * IMG_BYTES + IMG_BYTES, wave, t + BWD_NST - 1);
+      lk.issue(smem + ns * 2 * IMG_BYTES, wave, ord.tile(t + BWD_NST - 1));
+      lv.issue(smem + ns * 2 * IMG_BYTES + IMG_BYTES, wave, ord.tile(t + BWD_NST - 1));
     }
     const XVIT_LDS char* kimg = smem + stage * 2 * IMG_BYTES;
     const XVIT_LDS char* vimg = kimg + IMG_BYTES;
     stage = stage + 1 == BWD_NST ? 0 : stage + 1;
     if (!wave_active) continue;
-    const int nkb = (N - t * TILE_ROWS) > 32 ? 2 : 1;   // a tail tile with <= 32 keys needs one key block only
+    const int nkb = PEEL || (N - t * TILE_ROWS) > 32 ? 2 : 1;   // a tail tile with <= 32 keys needs one key block only (PEEL: 64 | NK, no tail)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       if (kb >= nkb) break;
@@ -506,7 +717,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16* __restr
       }
     }
   }
-  store_lane_rows(dqacc, scale, dq + off, sn, qrow, valid, lane);
+  store_lane_rows(dqacc, scale, dq + off, sn, qrow, valid, lane);   // dq has q's strides
+  if constexpr (PEEL && !(XVIT_PEEL_DEBUG & 1)) {
+    if (wave_active) {   // once per wave, after the loop: the CLS query (q0, dO0 in every column) against key block cls_kb of its own tile -> a partial of dQ0
+      const XVIT_LDS char* kimg = smem + ord.stage_of(cls_g, BWD_NST) * 2 * IMG_BYTES;
+      bf16x8 q0f[4], do0f[4];
+      lds_row_bcast(q0f, row0, lane);
+      lds_row_bcast(do0f, row0 + ROW0_BYTES, lane);
+      f32x16 dq0[2] = {ZERO16, ZERO16};
+      dq_block(rd, kimg, kimg + IMG_BYTES, cls_kb, q0f, do0f, c, nlse0, dlt0, dq0);
+      store_col0(dq0, pdq + ((((int64_t)b * H + head) * (NK / 32)) + cls_g) * 64, lane);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -517,58 +739,123 @@ constexpr int DKV_STAGE = 2 * IMG_BYTES + 512;  // Q image | dO image | nlse[64]
 // (198 VGPRs: two blocks per CU; bounding it to 168 for a third spills and measured 7 % slower; keeping the query-block loop
 // rolled gives 162 VGPRs without spills and three blocks per CU: 552 vs 563 us at B = 126, N = 513, but 50.4 vs 47.0 us at B = 8
 // and 1466 vs 1439 us at N = 4097 — not kept)
-template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
-                                                              int64_t sb, int64_t sn, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
-                                                              const float* __restrict__ nlse_ws, const float* __restrict__ delta,
-                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int H, int N, float scale, const DropArgs drop) {
+// one 32-query block of the dK/dV recomputation (keys on the lanes; or, for the CLS key, k0 / v0 repeated in every column):
+// S = Q K^T, dP = dO V^T -> P, dS -> dV^T += dO^T P, dK^T += Q^T dS.  st_lse / st_dlt: the tile's 64 query statistics in LDS
+__device__ __forceinline__ void dkv_block(const ImgReader& rd, const XVIT_LDS char* qimg, const XVIT_LDS char* doimg, const XVIT_LDS float* st_lse,
+                                          const XVIT_LDS float* st_dlt, int qb, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4], float c, int h,
+                                          f32x16 (&dkacc)[2], f32x16 (&dvacc)[2]) {
+  f32x16 s, dp, pr;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(qimg, qb, ks), kf[ks], ks == 0 ? ZERO16 : s, 0, 0, 0);
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.row_frag(doimg, qb, ks), vf[ks], ks == 0 ? ZERO16 : dp, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const f32x4 nl = *(const XVIT_LDS f32x4*)(st_lse + qb * 32 + 8 * g + 4 * h);
+    const f32x4 dl = *(const XVIT_LDS f32x4*)(st_dlt + qb * 32 + 8 * g + 4 * h);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float pv = __builtin_amdgcn_exp2f(fmaf(s[g * 4 + e], c, nl[e]));
+      pr[g * 4 + e] = pv;
+      s[g * 4 + e] = pv * (dp[g * 4 + e] - dl[e]);  // dS
+    }
+  }
+#pragma unroll
+  for (int ss = 0; ss < 2; ++ss) {
+    const bf16x8 pf = acc_frag(pr, ss), dsf = acc_frag(s, ss);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      dvacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(doimg, db, qb, ss), pf, dvacc[db], 0, 0, 0);
+      dkacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rd.tr_frag(qimg, db, qb, ss), dsf, dkacc[db], 0, 0, 0);
+    }
+  }
+}
+
+template <bool DROP, bool PEEL>
+__global__ __launch_bounds__(256, PEEL ? XVIT_DKV_PEEL_WAVES : 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
+                                                              int64_t sb, int64_t sn, const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
+                                                              const float* __restrict__ lse, const float* __restrict__ nlse_ws, const float* __restrict__ delta,
+                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int H, int N, float scale, const DropArgs drop,
+                                                              float* __restrict__ pdk, float* __restrict__ pdv) {
+  static_assert(!PEEL || !DROP, "the CLS peel is built without probability dropout");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
   const int lane = threadIdx.x & 63, wave = uniform(threadIdx.x >> 6);
   const BlockCoord bc = xcd_block_coord();
   const int b = bc.b, head = bc.head;
   const int k0 = bc.x * 128 + wave * 32;
-  const int64_t off = (int64_t)b * sb + head * DH;
-  const int64_t ooff = (int64_t)b * osb + head * DH;
-  const int64_t stat0 = ((int64_t)b * H + head) * N;
-  const int ntiles = (N + TILE_ROWS - 1) / TILE_ROWS;
+  const int NK = PEEL ? N - 1 : N;
+  const int64_t off0 = (int64_t)b * sb + head * DH, off = off0 + (PEEL ? sn : 0);
+  const int64_t ooff0 = (int64_t)b * osb + head * DH, ooff = ooff0 + (PEEL ? osn : 0);
+  const int64_t stat0 = ((int64_t)b * H + head) * N + (PEEL ? 1 : 0);
+  const int ntiles = (NK + TILE_ROWS - 1) / TILE_ROWS;
 
 #ifdef XVIT_DEBUG_ATTN_TIMES
   const uint64_t wc_entry = wall_clock64();
   uint64_t tk[4] = {0, 0, 0, 0};
 #endif
   TileLoader lq, ldo;
-  lq.init(q + off, sn, N, wave, lane);
-  ldo.init(d_o + ooff, osn, N, wave, lane);
+  lq.init(q + off, sn, NK, wave, lane);
+  ldo.init(d_o + ooff, osn, NK, wave, lane);
   // per-query statistics of a tile (64 floats each) also arrive by LDS-DMA (4 B per lane: even waves move nlse, odd waves
   // delta), so the loop contains NO ordinary global load whose compiler-inserted vmcnt(0) would drain the tile DMAs.
   // Rows past N read as 0 (buffer bounds): nlse = 0 gives P = 1 there, harmless because dO = 0 and delta = 0.
-  const __amdgpu_buffer_rsrc_t rstat = make_rsrc(((wave & 1) == 0 ? nlse_ws : delta) + stat0, clamp_bytes((int64_t)N * 4));
+  const __amdgpu_buffer_rsrc_t rstat = make_rsrc(((wave & 1) == 0 ? nlse_ws : delta) + stat0, clamp_bytes((int64_t)NK * 4));
   auto stage_stats = [&](XVIT_LDS char* st, int tile) {   // waves 2, 3 repeat waves 0, 1 (same bytes): every wave issues 5 DMAs per tile
     glds4(rstat, st + 2 * IMG_BYTES + (wave & 1) * 256, (uint32_t)(lane * 4), (uint32_t)(tile * TILE_ROWS * 4));
   };
+  TileOrder ord;
+  ord.init(PEEL, bc.x, ntiles);
+  XVIT_LDS char* row0 = smem + BWD_NST * DKV_STAGE;   // PEEL: [k0 | v0] (2 ROW0_BYTES)
+  if constexpr (PEEL) {
+    if (wave == 0) {
+      stage_row0(row0, k + off0, lane);
+      stage_row0(row0 + ROW0_BYTES, v + off0, lane);
+    }
+  }
 #pragma unroll
   for (int st = 0; st < BWD_NST - 1; ++st)
     if (st < ntiles) {
-      lq.issue(smem + st * DKV_STAGE, wave, st);
-      ldo.issue(smem + st * DKV_STAGE + IMG_BYTES, wave, st);
-      stage_stats(smem + st * DKV_STAGE, st);
+      lq.issue(smem + st * DKV_STAGE, wave, ord.tile(st));
+      ldo.issue(smem + st * DKV_STAGE + IMG_BYTES, wave, ord.tile(st));
+      stage_stats(smem + st * DKV_STAGE, ord.tile(st));
     }
 
   bf16x8 kf[4], vf[4];
-  load_lane_operand(kf, k + off, sn, k0, N, lane);
-  load_lane_operand(vf, v + off, sn, k0, N, lane);
+  load_lane_operand(kf, k + off, sn, k0, NK, lane);
+  load_lane_operand(vf, v + off, sn, k0, NK, lane);
   settle(kf);
   settle(vf);
   ImgReader rd;
   rd.init(lane);
   const int h = lane >> 5;
   const float c = scale * LOG2E;
-  const bool wave_active = k0 < N;   // wave-uniform
+  const bool wave_active = k0 < NK;   // wave-uniform
 
   f32x16 dkacc[2], dvacc[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dkacc[0][i] = 0.f; dkacc[1][i] = 0.f; dvacc[0][i] = 0.f; dvacc[1][i] = 0.f; }
+  // PEEL: the CLS query's row of P / dS is one scalar per key (lane), and its terms of dK[k] = sum_q dS[q, k] Q[q], dV[k] = sum_q P[q, k] dO[q]
+  // are the initial accumulators dS[0, k] q0 and P[0, k] dO0.  This wave's CLS-KEY block: the queries with its own keys' indices
+  // (k0 / v0 in every column -> partials of dK0, dV0).
+  const int cls_g = bc.x * 4 + wave, cls_qb = cls_g & 1;
+  if constexpr (PEEL && !(XVIT_PEEL_DEBUG & 2)) {
+    bf16x8 q0f[4], do0f[4], o0f[4];
+    load_row_bcast(q0f, q + off0, lane);
+    load_row_bcast(do0f, d_o + ooff0, lane);
+    load_row_bcast(o0f, o + ooff0, lane);
+    const float nlse0 = -lse[((int64_t)b * H + head) * N] * LOG2E, dlt0 = frag_dot(o0f, do0f);
+    const float p0 = __builtin_amdgcn_exp2f(fmaf(frag_dot(kf, q0f), c, nlse0));
+    float ds0 = p0 * (frag_dot(vf, do0f) - dlt0);
+    f32x16 ra[2];
+    load_row_acc(ra, q + off0, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dkacc[0][i] = ds0 * ra[0][i]; dkacc[1][i] = ds0 * ra[1][i]; }
+    load_row_acc(ra, d_o + ooff0, lane);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dvacc[0][i] = p0 * ra[0][i]; dvacc[1][i] = p0 * ra[1][i]; }
+    asm volatile("" : "+v"(ds0));   // settle these loads before the tile loop: see settle()
+  }
 
 #ifdef XVIT_DEBUG_ATTN_TIMES
   const uint64_t wc_loop = wall_clock64();
@@ -588,9 +875,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
       int ns = stage + BWD_NST - 1;
       if (ns >= BWD_NST) ns -= BWD_NST;
       XVIT_LDS char* nxt = smem + ns * DKV_STAGE;
-      lq.issue(nxt, wave, t + BWD_NST - 1);
-      ldo.issue(nxt + IMG_BYTES, wave, t + BWD_NST - 1);
-      stage_stats(nxt, t + BWD_NST - 1);
+      lq.issue(nxt, wave, ord.tile(t + BWD_NST - 1));
+      ldo.issue(nxt + IMG_BYTES, wave, ord.tile(t + BWD_NST - 1));
+      stage_stats(nxt, ord.tile(t + BWD_NST - 1));
     }
     const XVIT_LDS char* qimg = smem + stage * DKV_STAGE;
     stage = stage + 1 == BWD_NST ? 0 : stage + 1;
@@ -598,7 +885,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
     const XVIT_LDS float* st_lse = (const XVIT_LDS float*)(qimg + 2 * IMG_BYTES);
     const XVIT_LDS float* st_dlt = st_lse + 64;
     if (!wave_active) continue;
-    const int nqb = (N - t * TILE_ROWS) > 32 ? 2 : 1;   // a tail tile with <= 32 queries needs one query block only
+    const int nqb = PEEL || (N - t * TILE_ROWS) > 32 ? 2 : 1;   // a tail tile with <= 32 queries needs one query block only (PEEL: no tail)
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       if (qb >= nqb) break;
@@ -649,9 +936,92 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const bf16* __rest
   return;
 #endif
   const int krow = k0 + (lane & 31);
-  const bool valid = krow < N;
+  const bool valid = krow < NK;
   store_lane_rows(dkacc, scale, dk + off, sn, krow, valid, lane);
   store_lane_rows(dvacc, 1.0f, dv + off, sn, krow, valid, lane);
+  if constexpr (PEEL && !(XVIT_PEEL_DEBUG & 1)) {
+    if (wave_active) {   // once per wave, after the loop: the CLS key (k0, v0 in every column) against query block cls_qb of its own tile -> partials of dK0, dV0
+      const XVIT_LDS char* qimg = smem + ord.stage_of(cls_g, BWD_NST) * DKV_STAGE;
+      const XVIT_LDS float* st_lse = (const XVIT_LDS float*)(qimg + 2 * IMG_BYTES);
+      bf16x8 k0f[4], v0f[4];
+      lds_row_bcast(k0f, row0, lane);
+      lds_row_bcast(v0f, row0 + ROW0_BYTES, lane);
+      f32x16 dk0[2] = {ZERO16, ZERO16}, dv0[2] = {ZERO16, ZERO16};
+      dkv_block(rd, qimg, qimg + IMG_BYTES, st_lse, st_lse + 64, cls_qb, k0f, v0f, c, h, dk0, dv0);
+      const int64_t slot = ((((int64_t)b * H + head) * (NK / 32)) + cls_g) * 64;
+      store_col0(dk0, pdk + slot, lane);
+      store_col0(dv0, pdv + slot, lane);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// CLS peel, row 0 of the outputs: one wave per (b, head), lane = d.  The waves' partials are added in slot order.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_cls_fwd_merge_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v, int64_t sb,
+                                                                 bf16* __restrict__ o, int64_t osb, float* __restrict__ lse, const float* __restrict__ cls_ws,
+                                                                 int BH, int H, int N, float scale) {
+  const int lane = threadIdx.x & 63, bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= BH) return;
+  const int b = bh / H, head = bh - b * H, G = (N - 1) / 32;
+  const int64_t off0 = (int64_t)b * sb + head * DH;
+  const float c = scale * LOG2E;
+  const float* ws = cls_ws + (int64_t)bh * G * CLS_SLOT;
+  // the (CLS, CLS) score, raw like the partial maxima, is the starting state; the partials follow in slot order, eight loads deep
+  float m = wave_sum(bf2f(q[off0 + lane]) * bf2f(k[off0 + lane]));
+  float acc = bf2f(v[off0 + lane]), l = 1.f;
+  for (int g0 = 0; g0 < G; g0 += 8) {
+    float mg[8], lg[8], og[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float* r = ws + (int64_t)min(g0 + j, G - 1) * CLS_SLOT;
+      mg[j] = r[64]; lg[j] = r[65]; og[j] = r[lane];
+    }
+    float mn = m;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mn = fmaxf(mn, mg[j]);   // (a repeated last slot cannot raise the maximum)
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+    acc *= alpha; l *= alpha; m = mn;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float w = g0 + j < G ? __builtin_amdgcn_exp2f((mg[j] - m) * c) : 0.f;
+      acc = fmaf(w, og[j], acc);
+      l = fmaf(w, lg[j], l);
+    }
+  }
+  o[(int64_t)b * osb + head * DH + lane] = f2bf(acc / l);
+  if (lane == 0) lse[(int64_t)bh * N] = m * scale + __logf(l);
+}
+
+__global__ __launch_bounds__(256) void attn_cls_bwd_merge_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v, int64_t sb,
+                                                                 const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb, const float* __restrict__ lse,
+                                                                 const float* __restrict__ pdq, const float* __restrict__ pdk, const float* __restrict__ pdv,
+                                                                 bf16* __restrict__ dq, bf16* __restrict__ dk, bf16* __restrict__ dv, int BH, int H, int N, float scale) {
+  const int lane = threadIdx.x & 63, bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bh >= BH) return;
+  const int b = bh / H, head = bh - b * H, G = (N - 1) / 32;
+  const int64_t off0 = (int64_t)b * sb + head * DH, ooff0 = (int64_t)b * osb + head * DH;
+  const float c = scale * LOG2E;
+  const float q0 = bf2f(q[off0 + lane]), k0 = bf2f(k[off0 + lane]), v0 = bf2f(v[off0 + lane]), o0 = bf2f(o[ooff0 + lane]), g0 = bf2f(d_o[ooff0 + lane]);
+  float sq = 0.f, sk = 0.f, sv = 0.f;
+  const int64_t base = (int64_t)bh * G * 64 + lane;
+  for (int gg = 0; gg < G; gg += 8) {   // slot order, eight slots (24 loads) in flight
+    float a[8], bb[8], cc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t at = base + (int64_t)min(gg + j, G - 1) * 64;
+      a[j] = pdq[at]; bb[j] = pdk[at]; cc[j] = pdv[at];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (gg + j < G) { sq += a[j]; sk += bb[j]; sv += cc[j]; }
+  }
+  // the (CLS, CLS) element: P00 = exp(s00 scale - lse0), dS00 = P00 (dO0 . v0 - dO0 . O0)
+  const float p00 = __builtin_amdgcn_exp2f(fmaf(wave_sum(q0 * k0), c, -lse[(int64_t)bh * N] * LOG2E));
+  const float ds00 = p00 * (wave_sum(g0 * v0) - wave_sum(g0 * o0));
+  dq[off0 + lane] = f2bf(scale * fmaf(ds00, k0, sq));
+  dk[off0 + lane] = f2bf(scale * fmaf(ds00, q0, sk));
+  dv[off0 + lane] = f2bf(fmaf(p00, g0, sv));
 }
 
 }  // namespace xvit
@@ -668,54 +1038,104 @@ static int attn_check(const char* who, int B, int H, int N, int dh, int64_t sb, 
 
 static DropArgs drop_args(float p, uint64_t seed) { return DropArgs{(uint32_t)(p * 16777216.0f), 1.0f / (1.0f - p), seed}; }
 
+// xvit_set_option("attn_peel"): 0 = never; 2 = token 0 off the tile grid whenever N = 64 m + 1 and no probability dropout; 1 (default) = that,
+// on grids of >= 2560 workgroups only.  On a grid the chip holds in one or two rounds a launch takes as long as its slowest
+// workgroup, and the peeled workgroup (8 tiles + token-0 prologue and post-loop block, then the merge launch) is not shorter than
+// the grid form's (9 tiles): B = 8, N = 513: 21.0 vs 17.5 us forward, 53 vs 44 us backward; B = 32: equal; B = 126: 165 vs 182, 514 vs 536;
+// B = 8, N = 4097 (3072 workgroups): 491 vs 523, 1423 vs 1460 (tools/attn_peel_bench.py, one box, interleaved).
+static std::atomic<int> g_attn_peel{1};
+namespace xvit { void set_attn_peel(int v) { g_attn_peel.store(v, std::memory_order_relaxed); } }
+static bool peel_shape(int B, int H, int N, float dropout_p) {
+  const int mode = g_attn_peel.load(std::memory_order_relaxed);
+  if (mode == 0 || N <= 1 || (N - 1) % 64 != 0 || dropout_p != 0.f) return false;
+  return mode == 2 || (int64_t)B * H * ((N - 1 + 127) / 128) >= 2560;
+}
+
+extern "C" int64_t xvit_attn_fwd_workspace_bytes(int B, int H, int N) {
+  if (B <= 0 || H <= 0 || !peel_shape(B, H, N, 0.f)) return 0;
+  return (int64_t)B * H * ((N - 1) / 32) * CLS_SLOT * 4;
+}
+extern "C" int64_t xvit_attn_bwd_workspace_bytes(int B, int H, int N) {
+  if (B <= 0 || H <= 0 || N <= 0) return 0;
+  return ((int64_t)2 * B * H * N + (peel_shape(B, H, N, 0.f) ? (int64_t)3 * B * H * ((N - 1) / 32) * 64 : 0)) * 4;
+}
+
 extern "C" int xvit_attn_fwd(const void* q, const void* k, const void* v, int64_t sb, int64_t sn, void* o, int64_t osb, int64_t osn, float* lse,
-                             int B, int H, int N, int dh, float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream) {
+                             int B, int H, int N, int dh, float scale, float dropout_p, uint64_t dropout_seed, float* workspace, int64_t workspace_bytes,
+                             xvit_stream_t stream) {
   XVIT_REQUIRE(q && k && v && o && lse, "xvit_attn_fwd: null pointer");
   XVIT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "xvit_attn_fwd: dropout_p must be in [0, 1)");
   if (int e = attn_check("xvit_attn_fwd", B, H, N, dh, sb, sn, osb, osn)) return e;
   // QB = 1 (32 queries per wave).  QB = 2 was measured: identical throughput at N = 512..4097 (the loop is bound by
   // softmax VALU issue, 12.4 VALU per MFMA at d_h = 64 — not by LDS reads or per-wave ILP) and worse at small batch.
-  const dim3 grid((N + 127) / 128, H, B), block(256);
+  const dim3 block(256);
   const DropArgs da = drop_args(dropout_p, dropout_seed);
+  hipStream_t s = (hipStream_t)stream;
+  if (workspace && peel_shape(B, H, N, dropout_p)) {   // token 0 off the tile grid (see "CLS peel" above); without a workspace: the general kernel
+    XVIT_REQUIRE(workspace_bytes >= xvit_attn_fwd_workspace_bytes(B, H, N) && ((uintptr_t)workspace & 15) == 0,
+                 "xvit_attn_fwd: workspace of %lld bytes, need %lld (xvit_attn_fwd_workspace_bytes), 16-byte aligned", (long long)workspace_bytes,
+                 (long long)xvit_attn_fwd_workspace_bytes(B, H, N));
+    const dim3 grid((N - 1 + 127) / 128, H, B);
+    hipLaunchKernelGGL((attn_fwd_kernel<1, false, true>), grid, block, FWD_NST * 2 * IMG_BYTES + ROW0_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+                       (bf16*)o, osb, osn, lse, H, N, scale, da, workspace);
+    hipLaunchKernelGGL(attn_cls_fwd_merge_kernel, dim3((B * H + 3) / 4), block, 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, (bf16*)o, osb, lse,
+                       (const float*)workspace, B * H, H, N, scale);
+    return check_launch("xvit_attn_fwd");
+  }
+  const dim3 grid((N + 127) / 128, H, B);
   if (dropout_p > 0.f)
-    hipLaunchKernelGGL((attn_fwd_kernel<1, true>), grid, block, FWD_NST * 2 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
-                       (bf16*)o, osb, osn, lse, H, N, scale, da);
+    hipLaunchKernelGGL((attn_fwd_kernel<1, true, false>), grid, block, FWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+                       (bf16*)o, osb, osn, lse, H, N, scale, da, (float*)nullptr);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<1, false>), grid, block, FWD_NST * 2 * IMG_BYTES, (hipStream_t)stream, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
-                       (bf16*)o, osb, osn, lse, H, N, scale, da);
+    hipLaunchKernelGGL((attn_fwd_kernel<1, false, false>), grid, block, FWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+                       (bf16*)o, osb, osn, lse, H, N, scale, da, (float*)nullptr);
   return check_launch("xvit_attn_fwd");
 }
 
+template <bool DROP, bool PEEL>
+static void launch_attn_bwd(const void* q, const void* k, const void* v, int64_t sb, int64_t sn, const void* o, const void* d_o, int64_t osb, int64_t osn,
+                            const float* lse, float* ws, void* dq, void* dk, void* dv, int B, int H, int N, float scale, DropArgs da, hipStream_t s) {
+  const int64_t total = (int64_t)B * H * N;
+  float* delta = ws;            // workspace = [2][B,H,N]: delta | -lse*log2e, then (PEEL) the dQ0 | dK0 | dV0 partials, [B,H,(N-1)/32,64] each
+  float* nlse = ws + total;
+  const int64_t slots = PEEL ? (int64_t)B * H * ((N - 1) / 32) * 64 : 0;
+  float *pdq = ws + 2 * total, *pdk = pdq + slots, *pdv = pdk + slots;
+  const int NK = PEEL ? N - 1 : N;
+  const dim3 grid((NK + 127) / 128, H, B), block(256);
+  // the dQ kernel first: it also leaves delta and -lse log2(e) of every query row in the workspace for the dK/dV kernel
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DROP, PEEL>), grid, block, BWD_NST * 2 * IMG_BYTES + (PEEL ? 2 * ROW0_BYTES : 0), s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+                     (const bf16*)o, (const bf16*)d_o, osb, osn, lse, nlse, delta, (bf16*)dq, H, N, scale, da, pdq);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DROP, PEEL>), grid, block, BWD_NST * DKV_STAGE + (PEEL ? 2 * ROW0_BYTES : 0), s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn,
+                     (const bf16*)o, (const bf16*)d_o, osb, osn, lse, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, da, pdk, pdv);
+  if (PEEL)
+    hipLaunchKernelGGL(attn_cls_bwd_merge_kernel, dim3((B * H + 3) / 4), block, 0, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, (const bf16*)o,
+                       (const bf16*)d_o, osb, lse, pdq, pdk, pdv, (bf16*)dq, (bf16*)dk, (bf16*)dv, B * H, H, N, scale);
+}
+
 extern "C" int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t sb, int64_t sn, const void* o, const void* d_o, int64_t osb,
-                             int64_t osn, const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H, int N, int dh, float scale,
-                             float dropout_p, uint64_t dropout_seed, xvit_stream_t stream) {
-  XVIT_REQUIRE(q && k && v && o && d_o && lse && delta && dq && dk && dv, "xvit_attn_bwd: null pointer");
+                             int64_t osn, const float* lse, float* workspace, int64_t workspace_bytes, void* dq, void* dk, void* dv, int B, int H, int N, int dh,
+                             float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream) {
+  XVIT_REQUIRE(q && k && v && o && d_o && lse && workspace && dq && dk && dv, "xvit_attn_bwd: null pointer");
   XVIT_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "xvit_attn_bwd: dropout_p must be in [0, 1)");
   if (int e = attn_check("xvit_attn_bwd", B, H, N, dh, sb, sn, osb, osn)) return e;
+  const bool peel = peel_shape(B, H, N, dropout_p);
+  const int64_t need = peel ? xvit_attn_bwd_workspace_bytes(B, H, N) : (int64_t)2 * B * H * N * 4;
+  XVIT_REQUIRE(workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0, "xvit_attn_bwd: workspace of %lld bytes, need %lld (xvit_attn_bwd_workspace_bytes), 16-byte aligned",
+               (long long)workspace_bytes, (long long)need);
   hipStream_t s = (hipStream_t)stream;
   static const bool lds_opt_in = [] {   // rings deeper than 3 stages need more than the default 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * DKV_STAGE);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * DKV_STAGE);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * 2 * IMG_BYTES);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * DKV_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * DKV_STAGE);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * DKV_STAGE + 2 * ROW0_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * 2 * IMG_BYTES);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BWD_NST * 2 * IMG_BYTES + 2 * ROW0_BYTES);
     return true;
   }();
   (void)lds_opt_in;
-  const int total = B * H * N;
-  float* nlse = delta + total;   // workspace = [2][B,H,N]: delta | -lse*log2e
-  const dim3 grid((N + 127) / 128, H, B), block(256);
   const DropArgs da = drop_args(dropout_p, dropout_seed);
-  if (dropout_p > 0.f) {
-    // the dQ kernel first: it also leaves delta and -lse log2(e) of every query row in the workspace for the dK/dV kernel
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)o,
-                       (const bf16*)d_o, osb, osn, lse, nlse, delta, (bf16*)dq, H, N, scale, da);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, block, BWD_NST * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
-                       osn, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, da);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, block, BWD_NST * 2 * IMG_BYTES, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)o,
-                       (const bf16*)d_o, osb, osn, lse, nlse, delta, (bf16*)dq, H, N, scale, da);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, block, BWD_NST * DKV_STAGE, s, (const bf16*)q, (const bf16*)k, (const bf16*)v, sb, sn, (const bf16*)d_o, osb,
-                       osn, nlse, delta, (bf16*)dk, (bf16*)dv, H, N, scale, da);
-  }
+  if (peel) launch_attn_bwd<false, true>(q, k, v, sb, sn, o, d_o, osb, osn, lse, workspace, dq, dk, dv, B, H, N, scale, da, s);
+  else if (dropout_p > 0.f) launch_attn_bwd<true, false>(q, k, v, sb, sn, o, d_o, osb, osn, lse, workspace, dq, dk, dv, B, H, N, scale, da, s);
+  else launch_attn_bwd<false, false>(q, k, v, sb, sn, o, d_o, osb, osn, lse, workspace, dq, dk, dv, B, H, N, scale, da, s);
   return check_launch("xvit_attn_bwd");
 }

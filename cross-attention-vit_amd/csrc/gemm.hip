@@ -1082,6 +1082,7 @@ extern "C" int xvit_set_option(const char* name, int value) {
   if (n == "gemm_tile") { XVIT_REQUIRE(value >= 0 && value <= 2, "xvit_set_option: gemm_tile must be 0 (auto), 1 (128x128 only) or 2 (256x256 whenever M, N >= 256)"); g_gemm_tile = value; return 0; }
   if (n == "gemm_group") { XVIT_REQUIRE(value >= 0 && value <= 4096, "xvit_set_option: gemm_group must be in [0, 4096]"); g_gemm_group = value; return 0; }
   if (n == "gemm_epilogue") { XVIT_REQUIRE(value == 0 || value == 1, "xvit_set_option: gemm_epilogue must be 0 (auto) or 1 (narrow)"); g_gemm_epi = value; return 0; }
+  if (n == "attn_peel") { XVIT_REQUIRE(value >= 0 && value <= 2, "xvit_set_option: attn_peel must be 0 (token 0 stays on the tile grid), 1 (auto: large grids) or 2 (whenever N = 64 m + 1)"); set_attn_peel(value); return 0; }
   set_error("xvit_set_option: unknown option '%s'", name);
   return XVIT_ERR_ARG;
 }

@@ -25,6 +25,7 @@ constexpr int kWave = 64;
 // ---- error plumbing (host) -----------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+void set_attn_peel(int v);   // xvit_set_option("attn_peel") -> attention.hip
 
 #define XVIT_REQUIRE(cond, ...)            \
   do {                                     \

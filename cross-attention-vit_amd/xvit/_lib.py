@@ -36,8 +36,8 @@ SIGNATURES = {
     "xvit_layernorm_fwd": [vp, vp, i64, i32, i64, vp, vp, f32, vp, i64, vp, i64, vp, vp, i32, i32, vp],
     "xvit_linear_f32": [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, vp, i64, vp, i64, vp, i64, f32, u64, vp, i64, vp],
     "xvit_layernorm_bwd": [vp, i64, vp, vp, i64, i32, i64, vp, vp, vp, vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, vp, i64, vp],
-    "xvit_attn_fwd": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
-    "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
+    "xvit_attn_fwd": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp, i64, vp],
+    "xvit_attn_bwd": [vp, vp, vp, i64, i64, vp, vp, i64, i64, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_attn_fwd_fp8": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, vp, i64, vp],
     "xvit_cls_xattn_fwd": [vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
@@ -60,7 +60,8 @@ SIGNATURES = {
     "xvit_adam_step": [vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string", "xvit_gemm_workspace_bytes", "xvit_linear_f32_workspace_bytes",
-                                    "xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes", "xvit_patch_embed_wgrad_workspace_bytes", "xvit_attn_fp8_workspace_bytes", "xvit_xattn_kv_wgrad_partials"])
+                                    "xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes", "xvit_patch_embed_wgrad_workspace_bytes", "xvit_attn_fp8_workspace_bytes", "xvit_xattn_kv_wgrad_partials",
+                                    "xvit_attn_fwd_workspace_bytes", "xvit_attn_bwd_workspace_bytes"])
 
 _lib = None
 
@@ -88,6 +89,9 @@ def load() -> C.CDLL:
         lib.xvit_xattn_kv_wgrad_partials.restype = C.c_int64
         lib.xvit_attn_fp8_workspace_bytes.argtypes = [i32, i32, i32, i32]
         lib.xvit_attn_fp8_workspace_bytes.restype = C.c_int64
+        for name in ("xvit_attn_fwd_workspace_bytes", "xvit_attn_bwd_workspace_bytes"):
+            getattr(lib, name).argtypes = [i32, i32, i32]
+            getattr(lib, name).restype = C.c_int64
         lib.xvit_patch_embed_wgrad_workspace_bytes.argtypes = [C.POINTER(PatchGeom), i32]
         lib.xvit_patch_embed_wgrad_workspace_bytes.restype = C.c_int64
         lib.xvit_version.restype = C.c_int

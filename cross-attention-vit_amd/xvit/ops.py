@@ -237,9 +237,12 @@ def attn_fwd(qkv, B, N, H, scale, dropout=(0.0, 0)):
     lse = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device)
     ld = _rows2d(qkv)
     p = qkv.data_ptr()
+    lib = _lib.load()
+    need = lib.xvit_attn_fwd_workspace_bytes(B, H, N) if dropout[0] == 0.0 else 0    # > 0: the CLS-peel form (include/xvit.h)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=qkv.device) if need else None
     _run("attn_fwd", 4.0 * B * H * N * N * dh, "flop",
-         lambda: _lib.load().xvit_attn_fwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), N * d, d, _ptr(lse), B, H, N, dh, scale,
-                                           float(dropout[0]), int(dropout[1]), _stream()),
+         lambda: lib.xvit_attn_fwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), N * d, d, _ptr(lse), B, H, N, dh, scale,
+                                   float(dropout[0]), int(dropout[1]), _ptr(ws), need, _stream()),
          "xvit_attn_fwd")
     return o, lse
 
@@ -265,13 +268,15 @@ def attn_bwd(qkv, o, d_o, lse, B, N, H, scale, dropout=(0.0, 0)):
     d = qkv.shape[1] // 3
     dh = d // H
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty(2, B, H, N, dtype=torch.float32, device=qkv.device)   # workspace: rowsum(do*o) | -lse*log2e
+    lib = _lib.load()
+    need = lib.xvit_attn_bwd_workspace_bytes(B, H, N)
+    ws = torch.empty(need // 4, dtype=torch.float32, device=qkv.device)   # rowsum(do*o) | -lse*log2e | CLS-peel partials
     ld = _rows2d(qkv)
     assert dqkv.stride(0) == ld and _rows2d(o) == d and _rows2d(d_o) == d
     p, g = qkv.data_ptr(), dqkv.data_ptr()
     _run("attn_bwd", 10.0 * B * H * N * N * dh, "flop",
-         lambda: _lib.load().xvit_attn_bwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), _ptr(d_o), N * d, d, _ptr(lse), _ptr(delta),
-                                           g, g + 2 * d, g + 4 * d, B, H, N, dh, scale, float(dropout[0]), int(dropout[1]), _stream()), "xvit_attn_bwd")
+         lambda: lib.xvit_attn_bwd(p, p + 2 * d, p + 4 * d, N * ld, ld, _ptr(o), _ptr(d_o), N * d, d, _ptr(lse), _ptr(ws), need,
+                                   g, g + 2 * d, g + 4 * d, B, H, N, dh, scale, float(dropout[0]), int(dropout[1]), _stream()), "xvit_attn_bwd")
     return dqkv
 
 

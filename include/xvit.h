@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define XVIT_VERSION 200 /* 0.2.0: ld_alt in xvit_layernorm_fwd/bwd, dropout in xvit_attn_*, xvit_patch_embed_*, xvit_attn_fwd_fp8, xvit_linear_f32, workspaces */
+#define XVIT_VERSION 300 /* 0.3.0: workspaces in xvit_attn_fwd/bwd (CLS peel), xvit_linear_f32_batched; 0.2.0: ld_alt in xvit_layernorm_fwd/bwd, dropout in xvit_attn_*, xvit_patch_embed_*, xvit_attn_fwd_fp8, xvit_linear_f32, workspaces */
 
 enum { XVIT_OK = 0, XVIT_ERR_ARG = -1, XVIT_ERR_UNSUPPORTED = -2 };
 enum { XVIT_BF16 = 0, XVIT_F32 = 1 };
@@ -149,11 +149,21 @@ int64_t xvit_layernorm_bwd_workspace_bytes(int rows, int d);
  * ---------------------------------------------------------------------------------------- */
 int xvit_attn_fwd(const void* q, const void* k, const void* v, int64_t stride_b, int64_t stride_n, void* o, int64_t o_stride_b,
                   int64_t o_stride_n, float* lse, int B, int H, int N, int dh, float scale, float dropout_p, uint64_t dropout_seed,
-                  xvit_stream_t stream);
-/* delta: caller-provided fp32 workspace of 2*B*H*N floats (rowsum(do*o), then -lse*log2e).  dq/dk/dv use the q/k/v strides. */
+                  float* workspace, int64_t workspace_bytes, xvit_stream_t stream);
+/* workspace: xvit_attn_bwd_workspace_bytes(B, H, N) bytes of fp32, 16-byte aligned (rowsum(do*o), -lse*log2e, CLS-peel partials).
+ * dq/dk/dv use the q/k/v strides. */
 int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t stride_b, int64_t stride_n, const void* o, const void* d_o,
-                  int64_t o_stride_b, int64_t o_stride_n, const float* lse, float* delta, void* dq, void* dk, void* dv, int B, int H,
-                  int N, int dh, float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
+                  int64_t o_stride_b, int64_t o_stride_n, const float* lse, float* workspace, int64_t workspace_bytes, void* dq, void* dk,
+                  void* dv, int B, int H, int N, int dh, float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
+/* CLS peel.  The reference's sequences are cls + P patch tokens (model_cross.py:195-196): N = 64 m + 1 at every BASELINE config with
+ * cubic power-of-two volumes (513, 1025, 4097).  On a tile grid token 0 costs one more 128-query block per (b, head) and one more
+ * 64-key tile per block.  With a workspace (xvit_attn_fwd_workspace_bytes > 0 <=> the shape qualifies: N % 64 == 1, no probability
+ * dropout, and under the default xvit_set_option("attn_peel", 1) a grid of >= 2560 workgroups; 2 = any grid, 0 = never) the kernels tile the patch tokens only; token 0 enters as the initial
+ * online-softmax state / initial gradient accumulators (as a key) and as one extra MFMA block per wave with partial results merged
+ * in a fixed order (as a query).  Same outputs (o, lse, dq, dk, dv for all N tokens), bit-reproducible; workspace == NULL keeps
+ * token 0 on the tile grid. */
+int64_t xvit_attn_fwd_workspace_bytes(int B, int H, int N);
+int64_t xvit_attn_bwd_workspace_bytes(int B, int H, int N);
 
 /* ------------------------------------------------------------------------------------------
  * CLS-query cross-attention (model_cross.py:91-99): one query row per (b, h) against N keys.

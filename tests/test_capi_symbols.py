@@ -25,7 +25,7 @@ def test_argument_errors_do_not_launch():
     a = _lib.GemmArgs()
     assert lib.xvit_gemm(C.byref(a), None) < 0
     assert b"M,N,K" in lib.xvit_last_error_string() or b"layout" in lib.xvit_last_error_string() or len(lib.xvit_last_error_string()) > 0
-    assert lib.xvit_attn_fwd(None, None, None, 0, 0, None, 0, 0, None, 1, 1, 1, 64, 1.0, 0.0, 0, None) < 0
+    assert lib.xvit_attn_fwd(None, None, None, 0, 0, None, 0, 0, None, 1, 1, 1, 64, 1.0, 0.0, 0, None, 0, None) < 0
     assert lib.xvit_layernorm_fwd(None, None, 0, 0, 0, None, None, 1e-5, None, 0, None, 0, None, None, 1, 8, None) < 0
     assert lib.xvit_linear_f32(None, 0, None, 0, None, None, 0, 4, 8, 24, 0, None, 0, None, 0, None, 0, 0.0, 0, None, 0, None) < 0
     assert lib.xvit_linear_f32_workspace_bytes(126, 768, 3072) > 0 and lib.xvit_linear_f32_workspace_bytes(0, 8, 16) == 0

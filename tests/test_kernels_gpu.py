@@ -11,6 +11,16 @@ from _util import assert_close, dev, randn, rel, rt
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _peel_on_any_grid():
+    """The kernel tests run tiny batches: take the CLS-peel form of the attention kernels whenever the SHAPE qualifies (N = 64 m + 1),
+    not only on the large grids the default heuristic picks it for."""
+    from xvit import ops
+    ops.set_option("attn_peel", 2)
+    yield
+    ops.set_option("attn_peel", 1)
+
+
 def _ops():
     from xvit import ops
     return ops
@@ -64,7 +74,8 @@ def test_layernorm_row0_from_other_tensor():
 
 
 # ------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize("B,H,N", [(2, 3, 17), (2, 2, 65), (1, 4, 130), (2, 12, 513), (1, 2, 64), (1, 1, 128), (1, 2, 1)])
+@pytest.mark.parametrize("B,H,N", [(2, 3, 17), (2, 2, 65), (1, 4, 130), (2, 12, 513), (1, 2, 64), (1, 1, 128), (1, 2, 1),
+                                   (3, 2, 129), (2, 3, 193), (1, 2, 1025)])   # N = 64 m + 1: the CLS-peel form (include/xvit.h)
 def test_attention_fwd_bwd(B, H, N):
     ops = _ops()
     d = H * 64
@@ -104,7 +115,7 @@ def _attn_bwd_emulated(q, k, v, o_dev, do, lse, scale):
     return dq, dk, dv
 
 
-@pytest.mark.parametrize("B,H,N", [(2, 12, 513), (1, 2, 3376), (1, 2, 4097), (2, 3, 130)])
+@pytest.mark.parametrize("B,H,N", [(2, 12, 513), (1, 2, 3376), (1, 2, 4097), (2, 3, 130), (2, 2, 193)])
 def test_attention_bwd_vs_bf16_emulating_oracle(B, H, N):
     """Gate with the kernels' own rounding points emulated (bf16 P and dS into the second product): 3e-3 = 1e-3 + one bf16
     output rounding, also at the long-sequence tile counts of configs[2] (N = 3376: 53 key tiles) and configs[4]
@@ -137,6 +148,64 @@ def test_attention_online_softmax_rescale_branch():
     o_ref, lse_ref = R.softmax_attention(q, k, v, 0.125)
     assert_close(o.reshape(B, N, 1, 64).permute(0, 2, 1, 3), o_ref, "rescale branch")
     assert_close(lse, lse_ref, "rescale lse")
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 3, 193), (2, 12, 513)])
+def test_attention_cls_peel_matches_tile_grid_form(B, H, N):
+    """N = 64 m + 1 runs with token 0 off the tile grid (xvit_attn_fwd_workspace_bytes > 0); xvit_set_option("attn_peel", 0)
+    keeps it on the grid.  Same function, different summation order / rounding points for token 0's row and column: outputs
+    agree to bf16 round-off, every row and column included (row 0 and key 0 are checked on their own)."""
+    ops = _ops()
+    d = H * 64
+    scale = 0.125
+    qd = rt(randn(B, N, 3 * d, seed=N + 3)).to(dev(), torch.bfloat16).reshape(B * N, 3 * d)
+    dod = rt(randn(B, N, d, seed=N + 4)).to(dev(), torch.bfloat16).reshape(B * N, d)
+    outs = []
+    for peel in (2, 0):
+        ops.set_option("attn_peel", peel)
+        try:
+            o, lse = ops.attn_fwd(qd, B, N, H, scale)
+            dqkv = ops.attn_bwd(qd, o, dod, lse, B, N, H, scale)
+        finally:
+            ops.set_option("attn_peel", 2)
+        outs.append((o.float().reshape(B, N, d), lse, dqkv.float().reshape(B, N, 3 * d)))
+    (o1, l1, g1), (o0, l0, g0) = outs
+    assert rel(o1, o0) < 3e-3 and rel(o1[:, 0], o0[:, 0]) < 3e-3, (rel(o1, o0), rel(o1[:, 0], o0[:, 0]))
+    assert float((l1 - l0).abs().max()) < 1e-4
+    assert rel(g1, g0) < 4e-3 and rel(g1[:, 0], g0[:, 0]) < 4e-3, (rel(g1, g0), rel(g1[:, 0], g0[:, 0]))
+    # bit-reproducible: the partials are merged in slot order
+    o2, lse2 = ops.attn_fwd(qd, B, N, H, scale)
+    assert torch.equal(o2.float().reshape(B, N, d), o1) and torch.equal(lse2, l1)
+    assert torch.equal(ops.attn_bwd(qd, o2, dod, lse2, B, N, H, scale).float().reshape(B, N, 3 * d), g1)
+
+
+def test_attention_cls_peel_extreme_scores():
+    """Rule 26 for the peeled form: (a) the CLS key dominates some rows (the initial state IS the maximum and every later tile
+    rescales nothing), (b) a late patch key dominates others (the initial state is rescaled away), (c) the CLS query's maximum
+    sits in one wave's key block (the merge weights of all other partials underflow towards 0)."""
+    ops = _ops()
+    B, H, N = 1, 1, 193
+    qkv = rt(randn(B, N, 192, seed=11))
+    qkv[0, 0, 64:128] = rt(qkv[0, 7, 0:64] * 6.0)      # (a) k[0] = 6 q[7]
+    qkv[0, 180, 64:128] = rt(qkv[0, 40, 0:64] * 6.0)   # (b) k[180] = 6 q[40]
+    qkv[0, 100, 64:128] = rt(qkv[0, 0, 0:64] * 6.0)    # (c) k[100] = 6 q[0]
+    qd = qkv.to(dev(), torch.bfloat16).reshape(N, 192)
+    o, lse = ops.attn_fwd(qd, B, N, H, 0.125)
+    q, k, v = (t.reshape(B, N, 1, 64).permute(0, 2, 1, 3).clone().requires_grad_() for t in qkv.split(64, dim=-1))
+    o_ref, lse_ref = R.softmax_attention(q, k, v, 0.125)
+    assert_close(o.reshape(B, N, 1, 64).permute(0, 2, 1, 3), o_ref, "peel, extreme scores")
+    assert_close(lse, lse_ref, "peel, extreme scores: lse")
+    do = rt(randn(B, N, 64, seed=12))
+    o_ref.backward(do.reshape(B, N, 1, 64).permute(0, 2, 1, 3))
+    dqkv = ops.attn_bwd(qd, o, do.to(dev(), torch.bfloat16).reshape(N, 64), lse, B, N, H, 0.125).float().cpu().reshape(B, N, 192)
+    dq, dk, dv = (t.reshape(B, N, 1, 64).permute(0, 2, 1, 3) for t in dqkv.split(64, dim=-1))
+    assert rel(dq, q.grad) < 6e-3 and rel(dk, k.grad) < 6e-3 and rel(dv, v.grad) < 4e-3, (rel(dq, q.grad), rel(dk, k.grad), rel(dv, v.grad))
+    # the rows the spikes touch, one by one (a saturated softmax row has dq ~ 0: measure against the typical row norm)
+    nq, nk = float(q.grad.norm()) / N ** 0.5, float(k.grad.norm()) / N ** 0.5
+    for row in (0, 7, 40, 100, 180):
+        eq = float((dq[0, 0, row] - q.grad[0, 0, row]).norm()) / (float(q.grad[0, 0, row].norm()) + 0.05 * nq)
+        ek = float((dk[0, 0, row] - k.grad[0, 0, row]).norm()) / (float(k.grad[0, 0, row].norm()) + 0.05 * nk)
+        assert eq < 2e-2 and ek < 2e-2, (row, eq, ek)
 
 
 # --------------------------------------------------------------------------- CLS cross-attention

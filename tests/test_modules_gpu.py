@@ -138,6 +138,21 @@ def _run_model(name, batch):
 
 @pytest.mark.parametrize("name,batch", [("tiny", 4), ("small", 2), ("base", 2)])
 def test_model_cross_vs_reference_golden(golden_dir, name, batch):
+    _check_model_vs_golden(golden_dir, name, batch)
+
+
+def test_model_cross_base_with_cls_peel_vs_reference_golden(golden_dir):
+    """configs[1] at its bench batch runs the attention kernels in their CLS-peel form (N = 513 = 64 m + 1; include/xvit.h); the
+    default heuristic keeps small grids on the tile-grid form, so force it here: same goldens, same gates."""
+    from xvit import ops
+    ops.set_option("attn_peel", 2)
+    try:
+        _check_model_vs_golden(golden_dir, "base", 2)
+    finally:
+        ops.set_option("attn_peel", 1)
+
+
+def _check_model_vs_golden(golden_dir, name, batch):
     g = np.load(os.path.join(golden_dir, f"model_cross_{name}.npz"))
     cfg, sd, img, labels, model, caps, logits, loss = _run_model(name, batch)
     assert str(g["img_sha256"]) == R.tensor_sha256(img)  # same inputs the reference saw

@@ -48,11 +48,12 @@ def dkv_times():
         o, lse = ops.attn_fwd(qkv, B, N, H, 0.125)
         d_o = torch.randn(B * N, d, device=dev).bfloat16()
         dqkv = torch.empty_like(qkv)
-        delta = torch.zeros(2, B, H, N, dtype=torch.float32, device=dev)
+        need = _lib.load().xvit_attn_bwd_workspace_bytes(B, H, N)
+        delta = torch.zeros(need // 4, dtype=torch.float32, device=dev)
         p, g, ld = qkv.data_ptr(), dqkv.data_ptr(), 3 * d
         for _ in range(3):
-            _lib.check(_lib.load().xvit_attn_bwd(p, p + 2 * d, p + 4 * d, N * ld, ld, o.data_ptr(), d_o.data_ptr(), N * d, d, lse.data_ptr(), delta.data_ptr(),
-                                                 g, g + 2 * d, g + 4 * d, B, H, N, dh, 0.125, torch.cuda.current_stream().cuda_stream), "xvit_attn_bwd")
+            _lib.check(_lib.load().xvit_attn_bwd(p, p + 2 * d, p + 4 * d, N * ld, ld, o.data_ptr(), d_o.data_ptr(), N * d, d, lse.data_ptr(), delta.data_ptr(), need,
+                                                 g, g + 2 * d, g + 4 * d, B, H, N, dh, 0.125, 0.0, 0, torch.cuda.current_stream().cuda_stream), "xvit_attn_bwd")
         torch.cuda.synchronize()
         nx, nfull = (N + 127) // 128, N // 128
         w = delta.flatten()[: B * H * nx * 32].view(B * H, nx, 4, 8)[:, :nfull].reshape(-1, 8).double().cpu()
