@@ -235,9 +235,12 @@ class MultiScaleBlock(nn.Module):
         """The M modality branches are independent until fusion (separate weights, :122)."""
         return self._parallel([(lambda x_=x_, block=block: block(x_)) for x_, block in zip(x, self.blocks)], list(x))
 
-    def forward(self, x, cls_only=False):
+    def forward(self, x, cls_only=False, exclusive=False):
         """cls_only (used by ModelCross for its last block, whose outputs are read through their CLS rows only): the
-        fusions return [B, 1, d] instead of re-attaching the new CLS token to a copy of the patch tokens."""
+        fusions return [B, 1, d] instead of re-attaching the new CLS token to a copy of the patch tokens.
+        exclusive (ModelCross only): every output has exactly one consumer, whose backward returns a fresh gradient tensor —
+        together with "the branch output was produced here and no forward hook saw it" that lets a fusion splice its CLS
+        rows into the branch output in place (XF.CrossFusionFn); a direct caller gets the reference's copying cat."""
         attn = self._branches(x)
         # every reader of a branch output (its own fusion, other fusions that take its patch tokens, the pass-through) gets
         # its own alias, so the gradients are summed by _FanOut instead of across streams inside the engine
@@ -261,7 +264,8 @@ class MultiScaleBlock(nn.Module):
                 # cls of i + patch tokens of j -> new cls, re-attached to i's own patch tokens (:140-142)
                 xi = alias[(i, "own", i)]
                 xj = xi if j == i else alias[(j, "tok", i)]
-                thunks.append(lambda xi=xi, xj=xj, blk=blk: XF.CrossFusionFn.apply(xi, xj, *_fusion_args(blk), not cls_only, _p(blk, blk.attn.fn.attn_drop)))
+                own = exclusive and len(self.blocks[i]) > 0 and not any(m._forward_hooks for m in self.blocks[i].modules())
+                thunks.append(lambda xi=xi, xj=xj, blk=blk, own=own: XF.CrossFusionFn.apply(xi, xj, *_fusion_args(blk), not cls_only, _p(blk, blk.attn.fn.attn_drop), own))
                 cross_count += 1
             else:
                 thunks.append(None)                                    # no fusion for this modality: its tokens pass through (:146)
@@ -316,7 +320,11 @@ class ModelCross(EpochStatsMixin, _Base):
         for k, blk in enumerate(self.transformer):                       # nn.Sequential of MultiScaleBlocks (model_cross.py:171)
             last = k == len(self.transformer) - 1                        # only x[m][:, 0] of the last block is read below (model_cross.py:203) ...
             observed = bool(blk._forward_hooks) or bool(self.transformer._forward_hooks)   # ... unless a hook wants the reference's full output
-            x = blk(x, cls_only=last and not observed)
+            # the block's outputs go to the next block's branches (SelfAttentionBlockFn: fresh gradients) or to the heads; with a
+            # hook on the block, or a next block without self blocks, somebody else may hold / alias them
+            nxt = None if last else self.transformer[k + 1]
+            sole = not observed and (last or all(len(b) > 0 for b in nxt.blocks))
+            x = blk(x, cls_only=last and not observed, exclusive=sole)
         per_mod = [XF.HeadFn.apply(x[m], self.norm[m].weight, self.norm[m].bias, self.mlp_head[m][0].weight, self.mlp_head[m][0].bias,
                                    self.mlp_head[m][3].weight, self.mlp_head[m][3].bias, self.norm[m].eps, _p(self, self.mlp_head[m][2]))
                    for m in range(self.num_modalities)]

@@ -484,18 +484,21 @@ class CrossFusionFn(Function):
     """out_i = cat(CrossAttentionBlock(cat(cls_i, patches_j)), patches_i)  (model_cross.py:140-142)."""
 
     @staticmethod
-    def forward(ctx, xi, xj, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wp, bp, ln2w, ln2b, w1, b1, w2, b2, H, eps, concat, p=0.0):
+    def forward(ctx, xi, xj, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wp, bp, ln2w, ln2b, w1, b1, w2, b2, H, eps, concat, p=0.0, exclusive=False):
         B, N, d = xi.shape
         sh = (SHADOWS.get(wq), SHADOWS.get(wk, wv), SHADOWS.get(wp), SHADOWS.get(w1), SHADOWS.get(w2))
         bkv = torch.cat((bk, bv)).detach()
         xi2, xj2 = _f32c(xi).reshape(B * N, d), _f32c(xj).reshape(B * N, d)
         seeds = drop_seeds(4) if p > 0.0 else (0, 0, 0, 0)
-        # concat: the output is x_i with its CLS rows replaced by the fused token (model_cross.py:142).  x_i has no other
-        # reader of those rows (the other fusions take its PATCH rows, the producing block saves its input, not its output), so
-        # the new rows are written IN PLACE and the block's output aliases x_i: no 166 MB copy per fusion.  The write goes
-        # through .data (no version bump: autograd must not take x_i's patch rows, saved by the other fusion, for modified)
-        # and the backward keeps a packed copy of the original CLS rows.  XVIT_CLS_INPLACE=0 restores the copying form.
-        inplace = concat and os.environ.get("XVIT_CLS_INPLACE", "1") == "1"
+        # concat: the output is x_i with its CLS rows replaced by the fused token (model_cross.py:142) — by default a copy, as
+        # the reference's torch.cat.  `exclusive` (set by MultiScaleBlock when ModelCross drives it, never by a direct caller):
+        # x_i was produced inside the block, nobody else holds it or reads its CLS rows (the other fusions take its PATCH rows,
+        # the producing block saves its input, not its output, no forward hook saw it), and this node's output has ONE consumer
+        # whose backward returns a fresh gradient tensor.  Then the new rows are written IN PLACE and the output aliases x_i (no
+        # 166 MB copy per fusion; the write goes through .data: autograd must not take x_i's patch rows, saved by the other
+        # fusion, for modified), the backward keeps a packed copy of the original CLS rows and replaces the CLS rows of the
+        # incoming gradient where they are.  XVIT_CLS_INPLACE=0 forces the copying form.
+        inplace = concat and exclusive and os.environ.get("XVIT_CLS_INPLACE", "1") == "1"
         y2, saved = cross_forward(xi2, xj2, B, N, H, eps, ln1w, ln1b, wq.detach(), bq, sh[1], bkv, wp.detach(), bp, ln2w, ln2b, w1.detach(), b1,
                                   w2.detach(), b2, p, seeds, pack_cls=inplace)
         ctx.drop = (p, seeds)
@@ -520,8 +523,8 @@ class CrossFusionFn(Function):
         dcat = dcat.reshape(B, N, d)
         # cls row -> x_i (normed-concat path + the un-normed residual path); patch rows -> x_j
         if concat:
-            # in-place form: the incoming gradient has this node as its only consumer (the block's output feeds one branch),
-            # so its CLS rows are replaced where they are
+            # exclusive form: the incoming gradient has this node as its only reader (see forward), so its CLS rows are replaced
+            # where they are; otherwise the caller's grad_outputs / a gradient shared with another node stays untouched
             dxi = dout if inplace else dout.clone()
         else:
             dxi = torch.zeros(B, N, d, dtype=torch.float32, device=dout.device)
@@ -530,7 +533,7 @@ class CrossFusionFn(Function):
         dxj[:, 0] = 0
         wk, wv = g["wkv"].split(d, dim=0)
         bk, bv = g["bkv"].split(d)
-        return (dxi, dxj, g["ln1w"], g["ln1b"], g["wq"], g["bq"], wk, bk, wv, bv, g["wp"], g["bp"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None, None)
+        return (dxi, dxj, g["ln1w"], g["ln1b"], g["wq"], g["bq"], wk, bk, wv, bv, g["wp"], g["bp"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------

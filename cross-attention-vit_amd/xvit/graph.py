@@ -38,6 +38,10 @@ class GraphedStep:
         for m in model.modules():
             if isinstance(m, torch.nn.Dropout) and m.p > 0 and model.training:
                 raise RuntimeError("GraphedStep: dropout is active; its host-side seeds cannot be captured (use p = 0 or eval)")
+        if os.environ.get("XVIT_FANOUT", "1") != "1" and os.environ.get("XVIT_GRAPH_STREAMS", "1") == "1":
+            # without the fan-out node a branch output read by two forked fusions has its gradients accumulated by the autograd
+            # engine ACROSS the side streams: exactly the pattern hipStreamEndCapture crashes on (tools/graph_capture_probe.py)
+            raise RuntimeError("GraphedStep: XVIT_FANOUT=0 cannot be captured with forked fusions; unset it, or set XVIT_GRAPH_STREAMS=branches (or 0)")
         self.model = model
         if hasattr(model, "_sync_flat_weights") and next(model.parameters()).is_cuda and os.environ.get("XVIT_FLAT_WEIGHTS", "1") != "0":
             model._sync_flat_weights()             # parameters move into the flat buffer at the first forward: alias them afterwards
@@ -63,6 +67,9 @@ class GraphedStep:
                 p.grad = None                      # gradients are (re)allocated from the graph's private pool
             with torch.cuda.graph(self.graph):
                 self.logits, self.loss = self._eager(zero=False)
+            # the graph holds raw addresses: remember where the parameters (and the flat weight buffers) live
+            self._ptrs = [p.data_ptr() for p in self.params]
+            self._flat = getattr(model, "_flat", None)
         finally:
             self._restore_env()                    # also when warm-up or capture raises: never leave the process in capture mode
 
@@ -84,6 +91,9 @@ class GraphedStep:
         return logits.detach(), loss.detach()
 
     def __call__(self, img=None, labels=None):
+        if any(p.data_ptr() != q for p, q in zip(self.params, self._ptrs)) or getattr(self.model, "_flat", None) is not self._flat:
+            raise RuntimeError("GraphedStep: the model's parameter storage changed after capture (model.to(...), a re-built flat weight buffer): "
+                               "the captured graph would keep training the old buffers; build a new GraphedStep")
         if img is not None:
             self.img.copy_(img, non_blocking=True)
         if labels is not None:

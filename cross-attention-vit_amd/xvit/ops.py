@@ -195,6 +195,15 @@ def linear_f32(x, W, bias=None, *, act=ACT_NONE, residual=None, want_z=False, wa
     M, K = x.shape
     N = W.shape[0]
     assert x.dtype == torch.float32 and W.dtype == torch.float32 and W.shape[1] == K
+    if K % 16 or x.data_ptr() % 16 or W.data_ptr() % 16 or x.stride(0) % 4 or W.stride(0) % 4:
+        # the kernel walks K in 16-byte steps of aligned rows: a width that is not a multiple of 16 (the reference accepts any
+        # hidden_dim / mlp_dim) or an oddly offset view is zero-padded into aligned scratch copies first (exact: the pad adds 0)
+        K16 = (K + 15) // 16 * 16
+        xp = torch.zeros(M, K16, dtype=torch.float32, device=x.device)
+        wp = torch.zeros(N, K16, dtype=torch.float32, device=x.device)
+        xp[:, :K].copy_(x)
+        wp[:, :K].copy_(W)
+        x, W, K = xp, wp, K16
     y = torch.empty(M, N, dtype=torch.float32, device=x.device)
     yb = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if want_bf16 else None
     zb = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if want_z else None

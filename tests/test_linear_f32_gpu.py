@@ -51,10 +51,24 @@ def test_linear_f32_dropout_mask_matches_xvit_dropout():
     assert torch.equal(y, ops.dropout(plain.contiguous(), p, seed))
 
 
-def test_linear_f32_rejects_bad_arguments():
-    from xvit import ops
-    with pytest.raises(RuntimeError):
-        ops.linear_f32(torch.zeros(4, 24, device=dev()), torch.zeros(8, 24, device=dev()))     # K not a multiple of 16
+def test_linear_f32_any_width_and_offset_views():
+    """The reference accepts any hidden_dim / mlp_dim and any view; the kernel needs K % 16 == 0 and 16-byte-aligned rows, so
+    ops.linear_f32 pads odd widths / misaligned views into aligned scratch copies (exact).  The raw C entry point still
+    refuses them loudly."""
+    from xvit import _lib, ops
+    for M, N, K in ((4, 8, 24), (5, 100, 200), (3, 7, 50)):
+        x, w, b = randn(M, K, seed=1), randn(N, K, seed=2, scale=K ** -0.5), randn(N, seed=3)
+        y, _, _ = ops.linear_f32(x.to(dev()), w.to(dev()), b.to(dev()))
+        assert rel(y, x.double() @ w.double().T + b.double()) < 2e-6
+    big = randn(9, 4 * 64 + 1, seed=4).to(dev())
+    xv = big[:, 1:1 + 64]                                           # rows start 4 bytes off a 16-byte boundary
+    w = randn(32, 64, seed=5).to(dev())
+    y, _, _ = ops.linear_f32(xv, w)
+    assert rel(y, xv.double().cpu() @ w.double().cpu().T) < 2e-6
+    x24, w24, y24 = torch.zeros(4, 24, device=dev()), torch.zeros(8, 24, device=dev()), torch.zeros(4, 8, device=dev())
+    rc = _lib.load().xvit_linear_f32(x24.data_ptr(), 24, w24.data_ptr(), 24, None, y24.data_ptr(), 8, 4, 8, 24, 0, None, 0, None, 0, None, 0, 0.0, 0, None, 0,
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc < 0 and b"multiple of 16" in _lib.load().xvit_last_error_string()
 
 
 def test_layernorm_and_cls_attention_fp32_io():

@@ -445,6 +445,63 @@ def test_inplace_cls_splice_equals_copying_form(monkeypatch):
         assert torch.equal(res["1"][1][k], res["0"][1][k]), k
 
 
+def test_multiscale_block_standalone_keeps_callers_tensors_intact():
+    """The in-place CLS splice is reserved for ModelCross (which knows every tensor has one owner).  Driven directly,
+    MultiScaleBlock behaves like the reference's torch.cat (model_cross.py:140-142): a forward hook on a branch keeps the
+    branch's own CLS rows, the caller's grad_outputs is not written to, and a gradient shared by two nodes stays whole."""
+    import xvit
+    cfg = R.make_config("small")
+    torch.manual_seed(0)
+    blk = xvit.MultiScaleBlock(cfg).to(dev())
+    blk.train()
+    d = R.derived(cfg)
+    B, N, dm = 2, d.N, cfg.hidden_dim
+    xs = [torch.randn(B, N, dm, device=dev(), requires_grad=True) for _ in range(cfg.num_modalities)]
+    seen = {}
+    h = blk.blocks[0].register_forward_hook(lambda m, i, o: seen.__setitem__("branch0", o))   # kept WITHOUT a clone
+    outs = blk(xs)
+    h.remove()
+    ref = blk.blocks[0](xs[0]).detach()
+    assert torch.equal(seen["branch0"].detach(), ref), "the hooked branch output was modified after the hook saw it"
+    assert not torch.equal(outs[0][:, 0].detach(), ref[:, 0]), "the fusion did not replace the CLS rows of its output"
+    assert torch.equal(outs[0][:, 1:].detach(), ref[:, 1:])
+    g = [torch.randn_like(o) for o in outs]
+    keep = [t.clone() for t in g]
+    grads = torch.autograd.grad(outs, xs, grad_outputs=g, retain_graph=True)
+    assert all(torch.equal(a, b) for a, b in zip(g, keep)), "backward wrote into the caller's grad_outputs"
+    # the same gradient object handed to two consumers: out0 + aux, with aux a second leaf
+    aux = torch.zeros_like(outs[0], requires_grad=True)
+    (g_x0, g_aux) = torch.autograd.grad((outs[0] + aux), (xs[0], aux), grad_outputs=g[0])
+    assert torch.equal(g_aux, keep[0]), "the gradient shared with the other addend was modified"
+    assert all(torch.isfinite(t).all() for t in grads) and torch.isfinite(g_x0).all()
+
+
+def test_model_cross_hook_on_a_branch_sees_the_branch_output():
+    """A forward hook anywhere inside a MultiScaleBlock's branch switches that fusion to the copying form: the hooked tensor
+    keeps the branch's CLS rows while the model's logits stay what they are without the hook."""
+    import xvit
+    cfg = R.make_config("small")
+    sd = R.make_state_dict(cfg, seed=1)
+    img, labels = R.make_inputs(cfg, 2, seed=1)
+    model = xvit.ModelCross(cfg).to(dev())
+    model.load_state_dict(sd)
+    model.eval()
+    with torch.no_grad():
+        base, _ = model(img.to(dev()), labels.to(dev()))
+    seen = {}
+    h = model.transformer[0].blocks[1][-1].register_forward_hook(lambda m, i, o: seen.__setitem__("o", o))
+    with torch.no_grad():
+        hooked, _ = model(img.to(dev()), labels.to(dev()))
+    h.remove()
+    assert torch.equal(base, hooked)
+    # recompute the branch alone: its CLS rows are what the hook must have kept
+    with torch.no_grad():
+        toks = xvit.functional.PatchEmbedFn.apply(img.to(dev()), model.patch_to_embedding.weight, model.patch_to_embedding.bias, model.cls_token,
+                                                  model.pos_embedding, model.patch_size, 0.0)
+        ref = model.transformer[0].blocks[1](toks[1])
+    assert torch.equal(seen["o"], ref)
+
+
 def test_fusion_kv_backward_low_rank_vs_dense(monkeypatch):
     """The fusion's K/V projection backward: low-rank kernels (default) against the dense chain (dkv tensor, two GEMMs, column sums;
     used when 2 H > 32 or d > 1024).  Same logits; gradients agree to the bf16 rounding of dkv that only the dense chain has."""
