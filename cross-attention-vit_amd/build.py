@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "xvit", "libxvit_hip.so")
 OBJ = os.path.join(HERE, "build")
-SOURCES = ["core.hip", "gemm.hip", "linear_f32.hip", "layernorm.hip", "attention.hip", "attention_fp8.hip", "cls_xattn.hip", "misc.hip", "metrics.hip"]
+SOURCES = ["core.hip", "gemm.hip", "linear_f32.hip", "layernorm.hip", "attention.hip", "attention_fp8.hip", "cls_xattn.hip", "head_linear.hip", "misc.hip", "metrics.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 
 

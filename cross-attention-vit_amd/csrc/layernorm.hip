@@ -59,8 +59,12 @@ __global__ __launch_bounds__(LN_WAVES * 64) void ln_fwd_kernel(const float* __re
   }
 }
 
+#ifndef XVIT_LNB_OCC
+#define XVIT_LNB_OCC 2      // waves per SIMD the d <= 768 backward is compiled for: 2 = 184 registers, no spills; 3 = 168 registers with 15 spilled
+                            // dwords, measured slower on the LN2 form (174 vs 150 us at 64 k rows; tools/ln_bench.py)
+#endif
 template <int V>
-__global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const bf16* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
+__global__ __launch_bounds__(LNB_WAVES * 64, V <= 3 ? XVIT_LNB_OCC : (V <= 4 ? 2 : 1)) void ln_bwd_kernel(const bf16* __restrict__ dy, int64_t lddy, const float* __restrict__ x,
                                                                const float* __restrict__ x_alt, int64_t ldx, int seq_len, int64_t ld_alt,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ dres, int64_t lddres,
@@ -82,31 +86,35 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const bf16* __re
     sx[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     sr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += gridDim.x * LNB_WAVES) {
+  // A row costs one trip to memory (x, dy and dres are all requested up front) and two wave reductions; with one row per wave at a
+  // time the kernel was bound by exactly that latency chain (87 % of wave time parked, 4.6 TB/s).  Two rows per wave are kept in
+  // flight: the second row's loads are issued before the first row's arithmetic starts.
+  struct RowIn { f32x4 xv[V], rv[V]; bf16x4 dv[V]; float mu, rs; };
+  auto load_row = [&](RowIn& in, int row) {
     const f32x4* xr = (const f32x4*)((x_alt && (row % seq_len) == 0) ? x_alt + (int64_t)(row / seq_len) * ld_alt : x + (int64_t)row * ldx);
     const bf16* dyr = dy + (int64_t)row * lddy;
-    const float mu = mean[row], rs = rstd[row];
-    f32x4 xh[V], gy[V];
-    float s1 = 0.f, s2 = 0.f;
+    in.mu = mean[row]; in.rs = rstd[row];
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const int c = lane + i * 64;
-      if (c < nv) {
-        const f32x4 xv = xr[c];
-        const bf16x4 dv = *(const bf16x4*)(dyr + c * 4);
+      const bool ok = c < nv;
+      in.xv[i] = ok ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+      in.dv[i] = ok ? *(const bf16x4*)(dyr + c * 4) : bf16x4{f2bf(0.f), f2bf(0.f), f2bf(0.f), f2bf(0.f)};
+      in.rv[i] = (ok && dres) ? *(const f32x4*)(dres + (int64_t)row * lddres + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto do_row = [&](const RowIn& in, int row) {
+    const float mu = in.mu, rs = in.rs;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float h = (xv[e] - mu) * rs, dyv = bf2f(dv[e]);
-          xh[i][e] = h;
-          gy[i][e] = dyv * g[i][e];
-          dg[i][e] += dyv * h;
-          db[i][e] += dyv;
-          s1 += gy[i][e];
-          s2 += gy[i][e] * h;
-        }
-      } else {
-        xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gy[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < V; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {     // columns past d: x - mu != 0 there, masked through dy = 0 and g = 0
+        const float h = (in.xv[i][e] - mu) * rs, dyv = bf2f(in.dv[i][e]), gyv = dyv * g[i][e];
+        dg[i][e] += dyv * h;
+        db[i][e] += dyv;
+        s1 += gyv;
+        s2 += gyv * h;
       }
     }
     const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
@@ -116,11 +124,11 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const bf16* __re
       if (c < nv) {
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs * (gy[i][e] - m1 - xh[i][e] * m2);
+        for (int e = 0; e < 4; ++e)    // x-hat and dy g are recomputed rather than kept: 24 registers per row in flight
+          o[e] = rs * (bf2f(in.dv[i][e]) * g[i][e] - m1 - (in.xv[i][e] - mu) * rs * m2);
         if (dres) {
-          const f32x4 rv = *(const f32x4*)(dres + (int64_t)row * lddres + c * 4);
-          o += rv;
-          sr[i] += rv;
+          o += in.rv[i];
+          sr[i] += in.rv[i];
         }
         sx[i] += o;
         *(f32x4*)(dx + (int64_t)row * lddx + c * 4) = o;
@@ -129,6 +137,24 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void ln_bwd_kernel(const bf16* __re
           *(bf16x4*)(dxb + (int64_t)row * lddxb + c * 4) = ob;
         }
       }
+    }
+  };
+  const int stride = gridDim.x * LNB_WAVES;
+  if constexpr (V <= 4) {
+    for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += 2 * stride) {
+      RowIn ra, rb;
+      const int row2 = row + stride;
+      const bool two = row2 < rows;     // wave-uniform
+      load_row(ra, row);
+      if (two) load_row(rb, row2);
+      do_row(ra, row);
+      if (two) do_row(rb, row2);
+    }
+  } else {                               // wide rows (d > 1024): one row fills the register file
+    for (int row = blockIdx.x * LNB_WAVES + wave; row < rows; row += stride) {
+      RowIn ra;
+      load_row(ra, row);
+      do_row(ra, row);
     }
   }
   // cross-wave reduction of the column partials through LDS in two rounds ([waves][2][d] each: dgamma|dbeta, then

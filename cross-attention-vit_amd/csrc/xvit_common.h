@@ -86,15 +86,51 @@ __device__ __forceinline__ s16x4 lds_read_tr16(const XVIT_LDS void* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((XVIT_LDS s16x4*)p);
 }
 
+// Wave-wide reductions, result in every lane.  Four DPP steps inside each 16-lane row (quad_perm, row_half_mirror, row_mirror: the
+// operand permutation rides on the VALU instruction itself) and two row / half exchanges (v_permlane16_swap, v_permlane32_swap):
+// eight VALU instructions, no LDS pipe.  (__shfl_xor compiles to ds_bpermute_b32: six dependent LDS round trips of ~100 cycles each,
+// which is what a one-row-per-wave LayerNorm spends its time waiting on.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void swap_rows16(float x, float& a, float& b) {   // (x of the even row, x of the odd row) of each row pair, in both rows
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t_;
+  const unsigned bits = __builtin_bit_cast(unsigned, x);
+  const u32x2_t_ r = __builtin_amdgcn_permlane16_swap(bits, bits, false, false);
+  const unsigned r0 = r.x, r1 = r.y;
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void swap_halves32(float x, float& a, float& b) {
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t_;
+  const unsigned bits = __builtin_bit_cast(unsigned, x);
+  const u32x2_t_ r = __builtin_amdgcn_permlane32_swap(bits, bits, false, false);
+  const unsigned r0 = r.x, r1 = r.y;
+  a = __builtin_bit_cast(float, r0);
+  b = __builtin_bit_cast(float, r1);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v += dpp_perm<0xB1>(v);    // quad_perm [1, 0, 3, 2]
+  v += dpp_perm<0x4E>(v);    // quad_perm [2, 3, 0, 1]
+  v += dpp_perm<0x141>(v);   // row_half_mirror
+  v += dpp_perm<0x140>(v);   // row_mirror
+  float a, b;
+  swap_rows16(v, a, b);
+  v = a + b;
+  swap_halves32(v, a, b);
+  return a + b;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = fmaxf(v, dpp_perm<0xB1>(v));
+  v = fmaxf(v, dpp_perm<0x4E>(v));
+  v = fmaxf(v, dpp_perm<0x141>(v));
+  v = fmaxf(v, dpp_perm<0x140>(v));
+  float a, b;
+  swap_rows16(v, a, b);
+  v = fmaxf(a, b);
+  swap_halves32(v, a, b);
+  return fmaxf(a, b);
 }
 
 // Combine a value across the two 32-lane halves of a wave (lane l with lane l ^ 32) in ONE VALU instruction:

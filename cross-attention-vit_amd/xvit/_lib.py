@@ -41,6 +41,11 @@ SIGNATURES = {
     "xvit_attn_fwd_fp8": [vp, vp, vp, i64, i64, vp, i64, i64, vp, i32, i32, i32, i32, f32, vp, i64, vp],
     "xvit_cls_xattn_fwd": [vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
+    "xvit_head_rows": [vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp],
+    "xvit_head_cols": [vp, i64, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, vp],
+    "xvit_head_wgrad": [vp, i64, vp, i64, i64, vp, i64, vp, i64, i32, i32, i32, vp],
+    "xvit_cls_softmax_fwd": [vp, i64, vp, i64, vp, i32, i32, i32, f32, vp],
+    "xvit_cls_softmax_bwd": [vp, i64, vp, vp, i64, vp, vp, i64, i32, i32, i32, f32, vp],
     "xvit_xattn_kv_dgrad": [vp, vp, vp, i64, i32, i32, i32, i32, vp],
     "xvit_xattn_kv_wgrad": [vp, vp, i64, vp, i32, i32, i32, i32, vp],
     "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, i32, i64, vp],

@@ -167,6 +167,7 @@ class _FanOut(torch.autograd.Function):
         total = gs[0]
         for g in gs[1:]:
             total = total + g
+        XF.keep(total, *gs)
         return total, None
 
 
@@ -213,10 +214,13 @@ class MultiScaleBlock(nn.Module):
         dev = tensors[0].device
         cur = torch.cuda.current_stream(dev)
         streams = _side_streams(dev, len(thunks), kind)
-        # While a HIP graph is being captured every tensor lives in the graph's private pool and the order of the replayed
-        # work is fixed by the captured fork/join edges: record_stream (an allocator hint for eager reuse) has nothing to
-        # protect there, and its deferred-event bookkeeping on pool blocks is what capture_end tripped over.
+        # While a HIP graph is being captured record_stream is not available (its deferred-event bookkeeping on private-pool
+        # blocks is what capture_end tripped over); what it protects — a block freed by its owner stream's pool while another
+        # stream still reads it — is prevented by keeping every tensor that crosses streams alive until the capture ends
+        # (XF.keep, see functional.py).
         capturing = torch.cuda.is_current_stream_capturing()
+        if capturing:
+            XF.keep(*tensors)
         for i in work:
             st = streams[i]
             st.wait_stream(cur)
@@ -229,6 +233,8 @@ class MultiScaleBlock(nn.Module):
             cur.wait_stream(streams[i])
             if not capturing:
                 outs[i].record_stream(cur)
+            else:
+                XF.keep(outs[i])
         return outs
 
     def _branches(self, x):

@@ -65,8 +65,11 @@ class GraphedStep:
             self.graph = torch.cuda.CUDAGraph()
             for p in self.params:
                 p.grad = None                      # gradients are (re)allocated from the graph's private pool
-            with torch.cuda.graph(self.graph):
-                self.logits, self.loss = self._eager(zero=False)
+            try:
+                with torch.cuda.graph(self.graph):
+                    self.logits, self.loss = self._eager(zero=False)
+            finally:
+                XF.release_capture_keep()         # tensors that crossed streams were kept alive up to here (functional.keep)
             # the graph holds raw addresses: remember where the parameters (and the flat weight buffers) live
             self._ptrs = [p.data_ptr() for p in self.params]
             self._flat = getattr(model, "_flat", None)

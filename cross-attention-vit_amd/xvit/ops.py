@@ -350,6 +350,74 @@ def xattn_kv_backward(coef, q, d_o, wkv_b, hn, B, N, H):
     return dhn, dW, db
 
 
+def head_rows(x, W, out, H, out_bf16=None):
+    """out[b, h, :] = x[b, 64h:64h+64] @ W[64h:64h+64, :] (xvit_head_rows; fp32, per head).  x fp32 [B, d]; W fp32 [d, d] (a master
+    weight); out fp32 and out_bf16 (optional): any tensors indexable as [b, h, c] with a unit last stride — e.g. a [H, B, d] slab
+    transposed to [B, H, d], or a [B, 16, d] GEMM operand buffer, whose head rows H .. 15 the kernel zeroes."""
+    B, d = x.shape
+    assert x.dtype == torch.float32 and W.dtype == torch.float32 and out.dtype == torch.float32 and out.shape[-1] == d and out.stride(-1) == 1
+    ob = out_bf16
+    assert ob is None or (ob.dtype == torch.bfloat16 and ob.stride(-1) == 1)
+    _run("head_linear", 2.0 * B * d * 64, "flop",
+         lambda: _lib.load().xvit_head_rows(_ptr(x), _rows2d(x), _ptr(W), _rows2d(W), _ptr(out), out.stride(0), out.stride(1), _ptr(ob),
+                                            ob.stride(0) if ob is not None else 0, ob.stride(1) if ob is not None else 0, ob.shape[1] if ob is not None else 0,
+                                            B, H, d, _stream()), "xvit_head_rows")
+    return out
+
+
+def head_cols(t, W, H, row_scale=None, bias=None, want_bf16=False):
+    """out[b, 64h+e] = row_scale[b, h] * (t[b, h, :] . W[64h+e, :]) + bias[64h+e] (xvit_head_cols).  t fp32 [B, >=H, d] -> (fp32 [B, d], bf16 | None)."""
+    B, _, d = t.shape
+    assert t.dtype == torch.float32 and t.stride(2) == 1 and W.dtype == torch.float32
+    out = torch.empty(B, d, dtype=torch.float32, device=t.device)
+    ob = torch.empty(B, d, dtype=torch.bfloat16, device=t.device) if want_bf16 else None
+    _run("head_linear", 2.0 * B * d * 64, "flop",
+         lambda: _lib.load().xvit_head_cols(_ptr(t), t.stride(0), t.stride(1), _ptr(W), _rows2d(W), _ptr(row_scale), row_scale.stride(0) if row_scale is not None else 0,
+                                            _ptr(bias), _ptr(out), d, _ptr(ob), d, B, H, d, _stream()), "xvit_head_cols")
+    return out, ob
+
+
+def head_wgrad(x, t, H, row_scale=None):
+    """dW[64h+e, :] = sum_b x[b, 64h+e] row_scale[b, h] t[b, h, :] (xvit_head_wgrad) -> fp32 [d, d]."""
+    B, d = x.shape
+    assert x.dtype == torch.float32 and t.dtype == torch.float32 and t.stride(2) == 1 and t.shape[0] == B and t.shape[2] == d
+    dW = torch.empty(d, d, dtype=torch.float32, device=x.device)
+    _run("head_linear", 2.0 * B * d * 64, "flop",
+         lambda: _lib.load().xvit_head_wgrad(_ptr(x), _rows2d(x), _ptr(t), t.stride(0), t.stride(1), _ptr(row_scale), row_scale.stride(0) if row_scale is not None else 0,
+                                             _ptr(dW), d, B, H, d, _stream()), "xvit_head_wgrad")
+    return dW
+
+
+def cls_softmax_fwd(s, H, scale):
+    """s fp32 [B, N, 16] (scores of the H heads in the first columns) -> (e bf16 [B, N, 16] = exp(scale (s - max_n s)), zero past H; rz fp32 [B, H] = 1 / sum_n e)."""
+    B, N, ld = s.shape
+    assert s.dtype == torch.float32 and s.is_contiguous() and ld == 16
+    e = torch.empty(B, N, 16, dtype=torch.bfloat16, device=s.device)
+    rz = torch.empty(B, H, dtype=torch.float32, device=s.device)
+    _run("cls_softmax", B * N * 16 * 6.0, "byte", lambda: _lib.load().xvit_cls_softmax_fwd(_ptr(s), ld, _ptr(e), 16, _ptr(rz), B, H, N, scale, _stream()), "xvit_cls_softmax_fwd")
+    return e, rz
+
+
+def cls_softmax_bwd(e, rz, dp, H, scale):
+    """-> (coef fp32 [B, N, 2H] = (ds | p), ds bf16 [B, N, 16]); p = e rz, ds = scale p (dp - sum_n p dp)."""
+    B, N, _ = e.shape
+    assert e.dtype == torch.bfloat16 and e.is_contiguous() and dp.dtype == torch.float32 and dp.is_contiguous() and dp.shape == (B, N, 16)
+    coef = torch.empty(B, N, 2 * H, dtype=torch.float32, device=e.device)
+    dsb = torch.empty(B, N, 16, dtype=torch.bfloat16, device=e.device)
+    _run("cls_softmax", B * N * (16 * 8.0 + 2 * H * 4.0), "byte",
+         lambda: _lib.load().xvit_cls_softmax_bwd(_ptr(e), 16, _ptr(rz), _ptr(dp), 16, _ptr(coef), _ptr(dsb), 16, B, H, N, scale, _stream()), "xvit_cls_softmax_bwd")
+    return coef, dsb
+
+
+def xattn_kv_dgrad(coef, R, B, N, H, d):
+    """dhn[b, n, :] (bf16) = sum_j coef[b, n, j] R[j, b, :] (xvit_xattn_kv_dgrad); coef fp32 [B, N, 2H], R fp32 [2H, B, d]."""
+    assert coef.is_contiguous() and R.is_contiguous() and R.shape == (2 * H, B, d)
+    dhn = torch.empty(B * N, d, dtype=torch.bfloat16, device=coef.device)
+    _run("xattn_kv_dgrad", B * N * d * 2.0 + B * N * 2 * H * 4.0, "byte",
+         lambda: _lib.load().xvit_xattn_kv_dgrad(_ptr(coef), _ptr(R), _ptr(dhn), d, B, H, N, d, _stream()), "xvit_xattn_kv_dgrad")
+    return dhn
+
+
 def patchify(img, patch, pad_cls_row=False, concat=False):
     """img [B, M, 1, D, H, W] fp32|bf16 contiguous -> bf16 patch rows.
       default            [M, B*P, pd]           per modality, no padding

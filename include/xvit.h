@@ -190,6 +190,29 @@ int xvit_xattn_kv_dgrad(const float* coef, const float* R, void* dhn_bf16, int64
 int64_t xvit_xattn_kv_wgrad_partials(int B, int H, int N, int d);
 int xvit_xattn_kv_wgrad(const float* coef, const void* hn_bf16, int64_t ldh, float* part, int B, int H, int N, int d, xvit_stream_t stream);
 
+/* The fusion's key / value path in its low-rank form (model_cross.py:88-99): with one query row per (sample, head),
+ *   scores[b, n, h] = hn[b, n, :] . U[b, h, :] (+ a constant over n),  U[b, h, :] = q[b, h, :] Wk[64 h .. 64 h + 63, :]          (xvit_head_rows)
+ *   out[b, 64 h + e] = rz[b, h] sum_c Wv[64 h + e, c] S[b, h, c] + bv[64 h + e],  S[b, h, :] = sum_n e[b, n, h] hn[b, n, :]       (xvit_head_cols)
+ * so wk and wv are never applied to the N tokens: the two passes over hn are batched xvit_gemm calls ([N, d] x [d, 16] and
+ * [16, N] x [N, d] per sample) and the softmax over n sits between them (xvit_cls_softmax_fwd: bf16 weights e = exp(scale (s - max)),
+ * rz = 1 / sum e).  Backward: dp = hn . Y (Y = dO_h Wv_h, xvit_head_rows), xvit_cls_softmax_bwd -> coef (the input of
+ * xvit_xattn_kv_dgrad) and bf16 ds, T = sum_n ds hn (xvit_gemm), dq = Wk_h T (xvit_head_cols), dWk_h = q_h^T T, dWv_h = dO_h^T (rz S)
+ * (xvit_head_wgrad).  All per-head products are fp32 on the f32-input MFMA against the fp32 master weights; d = 64 H, H <= 16.
+ *   xvit_head_rows : out[b, h, c] (fp32, element strides out_sb / out_sh; optional bf16 copy with its own strides) = sum_e x[b, 64 h + e] W[64 h + e, c]
+ *   xvit_head_cols : out[b, 64 h + e] (fp32, row stride ldo; optional bf16 copy) = row_scale[b, h] * sum_c t[b, h, c] W[64 h + e, c] + bias[64 h + e]
+ *   xvit_head_wgrad: dW[64 h + e, c] = sum_b x[b, 64 h + e] row_scale[b, h] t[b, h, c]                                                   */
+int xvit_head_rows(const float* x, int64_t ldx, const float* W, int64_t ldw, float* out, int64_t out_sb, int64_t out_sh, void* out_bf16, int64_t ob_sb,
+                   int64_t ob_sh, int ob_heads, int B, int H, int d, xvit_stream_t stream);   /* head rows H .. ob_heads - 1 of the bf16 copy are zeroed */
+int xvit_head_cols(const float* t, int64_t t_sb, int64_t t_sh, const float* W, int64_t ldw, const float* row_scale, int64_t rs_ld, const float* bias,
+                   float* out, int64_t ldo, void* out_bf16, int64_t ldob, int B, int H, int d, xvit_stream_t stream);
+int xvit_head_wgrad(const float* x, int64_t ldx, const float* t, int64_t t_sb, int64_t t_sh, const float* row_scale, int64_t rs_ld, float* dW, int64_t lddw,
+                    int B, int H, int d, xvit_stream_t stream);
+/* s [B, N, lds] fp32 -> e [B, N, lde] bf16 (columns >= H zeroed; lde <= 16), rz [B, H] */
+int xvit_cls_softmax_fwd(const float* s, int64_t lds, void* e_bf16, int64_t lde, float* rz, int B, int H, int N, float scale, xvit_stream_t stream);
+/* p = e rz; ds = scale p (dp - sum_n p dp) -> coef [B, N, 2 H] fp32 = (ds | p), ds_bf16 [B, N, ldb] (columns >= H zeroed) */
+int xvit_cls_softmax_bwd(const void* e_bf16, int64_t lde, const float* rz, const float* dp, int64_t ldp, float* coef, void* ds_bf16, int64_t ldb, int B, int H,
+                         int N, float scale, xvit_stream_t stream);
+
 /* MX-fp8 forward attention (BASELINE.json configs[4] "fp8 MFMA QK^T/AV path"; reference ops model_cross.py:55-59):
  * same arguments and outputs as xvit_attn_fwd without dropout, but q, k, v are first quantised to OCP e4m3 with one e8m0
  * scale per 32 contraction elements (q, k along d_h; v transposed, along the keys) into the caller's workspace, and both

@@ -304,11 +304,30 @@ def self_block(sd, p, x, H):
 def cls_cross_attention(sd, p, x, H):
     """model_cross.py:88-102: the query is row 0 only; keys/values are all N rows."""
     d = x.shape[-1]
+    if _QUANT is not None and d == 64 * H and H <= 16:
+        return _cls_cross_attention_lowrank_emulated(sd, p, x, H)
     q = _split_heads(linear(x[:, 0:1], sd[p + ".wq.weight"], sd[p + ".wq.bias"], exact=True), H)
     k = _split_heads(linear(x, sd[p + ".wk.weight"], sd[p + ".wk.bias"], store=True), H)
     v = _split_heads(linear(x, sd[p + ".wv.weight"], sd[p + ".wv.bias"], store=True), H)
     o, _ = softmax_attention(q, k, v, (d // H) ** -0.5)
     return linear(_merge_heads(o), sd[p + ".proj.weight"], sd[p + ".proj.bias"], exact=True)
+
+
+def _cls_cross_attention_lowrank_emulated(sd, p, x, H):
+    """Emulation mode only: the rounding points of the HIP path's low-rank form (csrc/head_linear.hip).  Same function as
+    cls_cross_attention in exact arithmetic — scores[n] = q_h . (Wk_h x[n] + bk_h) = x[n] . (q_h Wk_h) + const, and
+    sum_n p[n] (Wv_h x[n] + bv_h) = Wv_h (sum_n p[n] x[n]) + bv_h — but K and V are never formed (so never rounded):
+    bf16 are the normed tokens x, the H vectors U_h = q_h Wk_h and the un-normalised softmax weights; wq, wk, wv, proj run fp32."""
+    B, N, d = x.shape
+    dh = d // H
+    xq = _q(x)
+    q = linear(x[:, 0], sd[p + ".wq.weight"], sd[p + ".wq.bias"], exact=True).reshape(B, H, dh)
+    U = torch.einsum("bhe,hec->bhc", q, sd[p + ".wk.weight"].reshape(H, dh, d))
+    sc = torch.einsum("bnc,bhc->bnh", xq, _q(U)) * dh ** -0.5
+    e = _q(torch.exp(sc - sc.amax(dim=1, keepdim=True)))
+    S = torch.einsum("bnh,bnc->bhc", e, xq) / e.sum(dim=1)[:, :, None]
+    o = torch.einsum("bhc,hec->bhe", S, sd[p + ".wv.weight"].reshape(H, dh, d)).reshape(B, 1, d) + sd[p + ".wv.bias"]
+    return linear(o, sd[p + ".proj.weight"], sd[p + ".proj.bias"], exact=True)
 
 
 def cross_block(sd, p, x, H):

@@ -32,3 +32,13 @@ def assert_close(out, ref, what=""):
     assert torch.isfinite(out.float()).all(), f"{what}: non-finite output"
     assert e <= tol, f"{what}: rel-L2 {e:.3e} > {tol:g} ({out.dtype})"
     return e
+
+
+def note(name, value):
+    """Record a measured distance (XVIT_MEASURE_LOG=path appends "name value"): how the stated gates were calibrated."""
+    import os
+    path = os.environ.get("XVIT_MEASURE_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{name} {value:.4e}\n")
+    return value

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 import ref_cpu as R
-from _util import assert_close, dev, randn, rel, rt
+from _util import note, assert_close, dev, randn, rel, rt
 
 pytestmark = pytest.mark.gpu
 
@@ -110,7 +110,7 @@ def test_model_cross_trains_with_reference_dropout_rates():
     e2, _ = model(img.to(dev()), labels.to(dev()))
     assert torch.equal(e1, e2)
     ref_logits, _ = R.model_cross_forward(R.make_state_dict(cfg, seed=0), img, labels, R.make_config("tiny"))
-    assert rel(e1, ref_logits) < 2.5e-2
+    assert note("dropout.eval_logits_vs_fp32", rel(e1, ref_logits)) < 1.1e-2      # measured 7.4e-3 (tiny config, eval mode, vs the fp32 oracle)
 
 
 @pytest.mark.parametrize("B,H,N", [(2, 3, 65), (1, 2, 200), (1, 12, 513)])

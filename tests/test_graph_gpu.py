@@ -66,3 +66,34 @@ def test_graphed_step_survives_a_stale_autograd_graph():
     assert float(loss_g) == float(loss.detach())
     for k, p in model.named_parameters():
         assert rel(p.grad, ref[k]) < 1e-5 or float(ref[k].abs().max()) < 1e-6, k
+
+
+@pytest.mark.parametrize("name,batch", [("small", 3), ("base", 2)])
+def test_graphed_step_replays_with_new_inputs_on_forked_fusions(name, batch):
+    """Three modalities in a ring / the configs[1] shape, fusions forked on side streams inside the capture: a replay with NEW inputs must
+    give that input's eager gradients.  (Round 3 found a latent reuse race here: a branch output read by another modality's fusion was
+    freed by its owner stream's pool while that fusion's backward, a parallel graph branch, still read it — functional.keep.)"""
+    import xvit
+    from xvit.graph import GraphedStep
+    cfg = R.make_config(name)
+    model = xvit.ModelCross(cfg).to(dev())
+    model.load_state_dict(R.make_state_dict(cfg, seed=0))
+    model.train()
+    ins = [tuple(t.to(dev()) for t in R.make_inputs(cfg, batch, seed=s)) for s in (0, 5)]
+
+    def eager(img, lab):
+        for p in model.parameters():
+            p.grad = None
+        logits, loss = model(img, lab)
+        loss.backward()
+        return logits.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    refs = [eager(*i) for i in ins]
+    step = GraphedStep(model, *ins[0])
+    for which in (0, 1, 1, 0):
+        logits, _ = step(*ins[which])
+        torch.cuda.synchronize()
+        assert torch.equal(logits, refs[which][0])
+        for k, p in model.named_parameters():
+            ref = refs[which][1][k]
+            assert rel(p.grad, ref) < 1e-5 or float(ref.abs().max()) < 1e-6, (which, k, rel(p.grad, ref))

@@ -167,3 +167,21 @@ def test_step_metrics_restatement_vs_scikit_learn():
     ep = R.epoch_metrics(cases)
     n = sum(len(l) for _, l in cases)
     assert abs(ep["acc"] - sum(R.binary_step_metrics(a, b)["acc"] * len(b) for a, b in cases) / n) < 1e-12
+
+
+def test_low_rank_emulation_is_the_same_function_as_the_literal_cross_attention():
+    """oracle/ref_cpu.py restates the fusion's attention twice: the reference's literal order (pinned against the reference) and,
+    for emulate_bf16(), the order of the HIP path's low-rank form.  With rounding switched off they must agree to fp32 round-off."""
+    import ref_cpu as R
+    cfg = R.make_config("tiny")
+    sd = R.make_state_dict(cfg, seed=2)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 17, cfg.hidden_dim, generator=g)
+    p = "transformer.0.fusion.0.attn.fn"
+    ref = R.cls_cross_attention(sd, p, x, cfg.num_heads)
+    prev, R._QUANT = R._QUANT, (lambda t: t)
+    try:
+        low = R.cls_cross_attention(sd, p, x, cfg.num_heads)
+    finally:
+        R._QUANT = prev
+    assert float((low - ref).norm() / ref.norm()) < 2e-6
