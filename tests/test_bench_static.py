@@ -25,4 +25,14 @@ def test_no_training_step_is_conditional_on_the_rank():
 
 def test_single_gpu_extras_are_gated_on_world_size_one():
     src = open(os.path.join(ROOT, "bench.py")).read()
-    assert "world == 1 and not args.no_clock_probe" in src and "world == 1 and not args.no_cpu_baseline" in src
+    assert "world == 1 and not use_dist and not args.no_small_batch" in src and "world == 1 and not args.no_cpu_baseline" in src
+
+
+def test_small_batch_points_run_in_a_child_process_after_the_headline():
+    """The optional small-batch points capture HIP graphs; a native crash there must not cost the headline line: they run in a fresh
+    `bench.py --small-batch-only` child (subprocess, never a re-exec of the GPU process), and the headline is already measured."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "--small-batch-only" in src and "subprocess.run([sys.executable, os.path.abspath(__file__), \"--small-batch-only\"]" in src
+    assert "os.exec" not in src
+    body = src[src.index("def main():"):]
+    assert body.index("small_batch_child()") > body.index("tokens_per_s = world * B * M * P * args.steps / dt")
