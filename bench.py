@@ -174,7 +174,7 @@ def dry_run(args, rank, world):
     dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "world": world, "pid": os.getpid()})
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks": seen}), flush=True)
+        emit({"dryrun": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks": seen})
     dist.destroy_process_group()
 
 
@@ -238,6 +238,27 @@ def small_batch_child(timeout=240):
         return {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
 
+_JSON_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a five-line version banner at
+    communicator creation): from here on file descriptor 1 is stderr for everybody, and emit() writes the line to the real stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode()); sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -263,6 +284,7 @@ def main():
         os.environ["XVIT_STREAMS"] = "0"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    claim_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -288,10 +310,11 @@ def main():
     model = xvit.ModelCross(cfg).to(dev)
     model.train()
     if args.small_batch_only:
-        print(json.dumps(small_batch_points(model, cfg, dev, P, (8, 32))), flush=True)
+        emit(small_batch_points(model, cfg, dev, P, (8, 32)))
         return
     params = [p for p in model.parameters()]
     reducer = BucketedGradReducer(params, bucket_bytes=32 << 20) if use_dist else None
+    exposed = []                          # (start, end) events around reducer.finish(): the time the compute stream waits for the collectives' tail
 
     gen = torch.Generator().manual_seed(1234 + rank)
     img = torch.randn(B, M, 1, *cfg.img_size, generator=gen).to(dev, torch.bfloat16)   # random (not zero) data: MI355X_MICROARCH.md DVFS note
@@ -304,14 +327,24 @@ def main():
         _, loss = model(img, labels)
         loss.backward()
         if reducer is not None:
-            reducer.finish()
+            if timing[0]:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                reducer.finish()
+                e1.record()
+                exposed.append((e0, e1))
+            else:
+                reducer.finish()
         return loss
 
+    timing = [False]
+    if reducer is not None:
+        import xvit.functional as XF
+        model(img, labels)                 # the first forward moves the weights into their flat buffers: map the sink afterwards
+        XF.GRAD_SINK = reducer.grad_sink(model)   # weight-gradient kernels write into the bucket views: no pack pass
     if args.graph:
-        if use_dist:
-            raise SystemExit("--graph is a single-GPU mode")
         from xvit.graph import GraphedStep
-        graphed = GraphedStep(model, img, labels)
+        graphed = GraphedStep(model, img, labels, reducer=reducer)   # N > 1: the bucket all-reduces are nodes of the captured graph
         eager_step = step
 
         def step():                                   # noqa: F811
@@ -331,11 +364,13 @@ def main():
             log("first step done")
     fence()
     log("warm-up done")
+    timing[0] = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    timing[0] = False
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -366,7 +401,11 @@ def main():
         except Exception:
             ver = None
         out["collective"] = {"backend": dist.get_backend(), "rccl_version": ver, "ranks": dist.get_world_size(),
-                             "buckets": len(reducer.buckets), "bucket_mib": 32, "exposed_launches": reducer.exposed_launches}
+                             "buckets": len(reducer.buckets), "bucket_mib": 32, "exposed_launches": reducer.exposed_launches,
+                             "gradient_sink": "weight gradients written into the bucket views (no pack copy); mean applied by the collective (ReduceOp.AVG)",
+                             "exposed_ms": round(sum(a.elapsed_time(b) for a, b in exposed) / max(len(exposed), 1), 3) if exposed else None,
+                             "exposed_ms_note": "per step, rank 0: time reducer.finish() holds the compute stream waiting for the tail of the bucket all-reduces "
+                                                "(eager launches; with --graph the collectives are nodes of the replayed graph and are not separable)"}
 
     # ---- per-kernel pricing with HIP events on the launch stream (rank 0) --------------------
     if args.graph:
@@ -443,7 +482,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
 

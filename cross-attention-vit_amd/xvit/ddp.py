@@ -10,6 +10,16 @@ all-reduce is issued immediately on a SIDE stream behind an event, so RCCL traff
 rest of backward; `finish()` makes the compute stream wait for the tail.  After `finish()` every
 `p.grad` is a view into its bucket (no copy back).
 
+No pack pass for the weight matrices: `grad_sink()` maps every 2-D parameter (by the address of the fp32 master and of
+its bf16 operand copy) to its bucket view, and with `xvit.functional.GRAD_SINK` set to it the weight-gradient kernels
+write straight into the buckets (the gradient autograd hands on IS the view); the 1/world of the mean rides on the
+collective itself (ReduceOp.AVG on RCCL).  What is left to copy are the 1-D gradients (biases, norms: 0.3 % of the bytes).
+
+With a captured step (`xvit.graph.GraphedStep(model, img, labels, reducer=...)`) the same logic runs from TENSOR hooks on
+the step's leaf aliases while the graph is being captured, so the bucket all-reduces become nodes of the graph, forked
+onto the comm stream behind the events of their last gradients and joined before the graph ends: a replay launches the
+whole step, collectives included, and they overlap the rest of the captured backward exactly as in the eager form.
+
 The class is device-agnostic (CPU tensors + gloo skip the stream logic), which is what the
 world_size-2 tests in tests/test_ddp_gloo.py run.
 """
@@ -24,12 +34,12 @@ class _Bucket:
 
     def __init__(self, params, device):
         self.params = params
-        n = sum(p.numel() for p in params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=device)
+        slot = lambda p: (p.numel() + 63) // 64 * 64          # noqa: E731 — every view starts on a 256-byte boundary: kernels write into them (16-byte stores)
+        self.flat = torch.zeros(sum(slot(p) for p in params), dtype=torch.float32, device=device)
         self.views, o = [], 0
         for p in params:
             self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
+            o += slot(p)
         self.pending, self.work, self.launched = len(params), None, False
         self.events = {}      # stream id -> (stream, event): the latest gradient write of this bucket on each stream
 
@@ -66,8 +76,27 @@ class BucketedGradReducer:
                 dist.broadcast(p.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
         self.buckets = [_Bucket(ps, self.device) for ps in plan_buckets(params, bucket_bytes)]
         self._bucket_of = {id(p): b for b in self.buckets for p in b.params}
+        self._view_of = {id(p): v for b in self.buckets for p, v in zip(b.params, b.views)}
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params]
         self.exposed_launches = 0
+        self._avg = self.cuda and dist.get_backend(process_group) == "nccl"     # RCCL applies the 1/world itself; gloo has no AVG
+        self._graph_mode = False
+
+    def grad_sink(self, model=None):
+        """{address -> bucket view} for every weight matrix: its fp32 master and, when `model` keeps a flat bf16 operand copy
+        (ModelCross: xvit.functional.FlatWeights), that copy's view.  Assign to xvit.functional.GRAD_SINK."""
+        sink = {}
+        for b in self.buckets:
+            for p, v in zip(b.params, b.views):
+                if p.dim() == 2:
+                    sink[p.data_ptr()] = v
+        flat = getattr(model, "_flat", None) if model is not None else None
+        if flat is not None:
+            for p, v16 in zip(flat.params, flat.view16):
+                v = self._view_of.get(id(p))
+                if v is not None:
+                    sink[v16.data_ptr()] = v
+        return sink
 
     # ---- per-gradient hook (runs inside backward) ----------------------------------------------
     def _on_grad(self, p):
@@ -85,9 +114,31 @@ class BucketedGradReducer:
         if b.pending == 0 and not b.launched:
             self._launch(b)
 
+    # ---- captured step: the same bookkeeping from tensor hooks on the step's leaf aliases (xvit.graph.GraphedStep) -----------
+    def attach_leaves(self, leaves):
+        """`leaves`: [(parameter, alias tensor the captured step differentiates)].  Returns hook handles.  Each alias gradient is
+        moved into its bucket view (a no-op for the weight matrices written there by the kernels) and counted like p.grad."""
+        handles = []
+        for p, a in leaves:
+            def hook(g, p=p):
+                v = self._view_of[id(p)]
+                if g.data_ptr() != v.data_ptr():
+                    v.copy_(g)
+                self._on_grad(p)
+                return None
+            handles.append(a.register_hook(hook))
+        return handles
+
+    def set_graph_mode(self, on: bool):
+        """While True the gradients are taken to sit in the bucket views already (attach_leaves put them there) and p.grad is not read."""
+        self._graph_mode = bool(on)
+
     def _launch(self, b):
         b.launched = True
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
+        if self._graph_mode:
+            grads = list(b.views)
+        else:
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b.params]
         scale = 1.0 / self.world
         if self.cuda:
             cur = torch.cuda.current_stream(self.device)
@@ -98,21 +149,25 @@ class BucketedGradReducer:
             with torch.cuda.stream(self.comm_stream):
                 for _, ev in b.events.values():        # every stream that wrote one of this bucket's gradients
                     self.comm_stream.wait_event(ev)
-                for g in grads:                        # allocated on a branch stream, last read here
-                    g.record_stream(self.comm_stream)
-                self._pack(b, grads, scale)
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if not torch.cuda.is_current_stream_capturing():
+                    for g in grads:                    # allocated on a branch stream, last read here
+                        g.record_stream(self.comm_stream)
+                self._pack(b, grads, None if self._avg else scale)
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             self._pack(b, grads, scale)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     @staticmethod
     def _pack(b, grads, scale):
+        """Gradients that are not in their bucket view yet (1-D ones; every one without a GRAD_SINK) are copied there; `scale` is
+        the 1/world of the mean where the collective cannot apply it itself."""
         srcs = [g for g, v in zip(grads, b.views) if g.data_ptr() != v.data_ptr()]
         dsts = [v for g, v in zip(grads, b.views) if g.data_ptr() != v.data_ptr()]
         if srcs:
             torch._foreach_copy_(dsts, srcs)
-        b.flat.mul_(scale)
+        if scale is not None:
+            b.flat.mul_(scale)
 
     # ---- after backward ------------------------------------------------------------------------
     def finish(self):

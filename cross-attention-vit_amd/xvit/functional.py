@@ -236,20 +236,36 @@ def _wgrad_stream(cur):
     return _WGRAD_STREAMS[key]
 
 
-def _wgrad(dy_b, x_b):
+# Data-parallel runs: xvit.ddp.BucketedGradReducer registers, for every weight matrix, the view of its all-reduce bucket under the
+# data_ptr of the fp32 master AND of its bf16 operand copy; a weight-gradient kernel then writes straight into the bucket (no pack
+# copy of 373 MB per step at configs[1]) and the tensor autograd hands on IS that view.
+GRAD_SINK = None
+
+
+def _grad_out(like, shape, device):
+    """Destination of a weight gradient: the reducer's bucket view registered for `like` (a master weight or its bf16 copy), else a fresh tensor."""
+    if GRAD_SINK is not None and like is not None:
+        v = GRAD_SINK.get(like.data_ptr())
+        if v is not None and tuple(v.shape) == tuple(shape):
+            return v.detach()                 # a fresh alias: autograd may take it over (its use count is 1)
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
+def _wgrad(dy_b, x_b, like=None):
     """dW[out, in] = dy^T x over all rows (tokens); fp32.  Weight gradients are off the critical path of a block's
     backward (nothing downstream reads them), so large ones are issued on a companion stream and overlap the
-    HBM-bound kernels of the dgrad chain; `_join_wgrads()` re-joins before the Function returns."""
+    HBM-bound kernels of the dgrad chain; `_join_wgrads()` re-joins before the Function returns.  `like`: the weight (or its
+    bf16 copy) this is the gradient of — see GRAD_SINK."""
     out_f, in_f, k = dy_b.shape[1], x_b.shape[1], dy_b.shape[0]
     cur = torch.cuda.current_stream(dy_b.device)
     ws = _wgrad_stream(cur) if k >= 1024 else None
     if ws is None:
-        dW = torch.empty(out_f, in_f, dtype=torch.float32, device=dy_b.device)
+        dW = _grad_out(like, (out_f, in_f), dy_b.device)
         ops.gemm(ops.TN, dy_b, x_b, dW, split_k=_wgrad_split(out_f, in_f, k))
         return dW
     ws.wait_stream(cur)                       # operands are produced on `cur`
     with torch.cuda.stream(ws):
-        dW = torch.empty(out_f, in_f, dtype=torch.float32, device=dy_b.device)
+        dW = _grad_out(like, (out_f, in_f), dy_b.device)
         ops.gemm(ops.TN, dy_b, x_b, dW, split_k=_wgrad_split(out_f, in_f, k))
     return dW
 
@@ -360,9 +376,9 @@ def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w
     dyb = _masked(ops.cast_bf16(dy), p_ffn, seeds[2])        # d(FFN out) = dy * mask
     # FFN
     dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"], dropout=_dp(p_ffn, seeds[1]), aux_mode=AUX_MODE)
-    g["w2"] = _wgrad(dyb, a)
+    g["w2"] = _wgrad(dyb, a, w2_s)
     dh2 = _dgrad(dz, w1_s)
-    g["w1"] = _wgrad(dz, h2)
+    g["w1"] = _wgrad(dz, h2, w1_s)
     # without dropout the two bias gradients are column sums LN2's backward produces anyway
     dx1, dx1b = ops.layernorm_bwd(dh2, x1, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy, want_bf16=True,
                                   dxsum=g["bo"] if p_out == 0.0 else None, dressum=g["b2"] if p_ffn == 0.0 else None)
@@ -373,10 +389,10 @@ def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w
         ops.colsum(dx1b, out=g["bo"], accumulate=True)
     # attention
     do = _dgrad(dx1b, wo_s)
-    g["wo"] = _wgrad(dx1b, o)
+    g["wo"] = _wgrad(dx1b, o, wo_s)
     dqkv = ops.attn_bwd(qkv, o, do, lse, B, N, H, scale, dropout=(p_attn, seed_attn))
     dh1 = _dgrad(dqkv, wqkv_s)
-    g["wqkv"] = _wgrad(dqkv, h1)
+    g["wqkv"] = _wgrad(dqkv, h1, wqkv_s)
     if has_bqkv:
         g["bqkv"] = ops.colsum(dqkv)
     dx, _ = ops.layernorm_bwd(dh1, x, mu1, rs1, ln1w, g["ln1w"], g["ln1b"], dres=dx1)
@@ -501,9 +517,9 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
     bk0 = g.pop("bk0")                                                    # stays zero: wk.bias has no gradient (softmax shift invariance)
     dyb = _masked(ops.cast_bf16(dy2), pd, seeds[3])
     dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"], dropout=_dp(pd, seeds[2]))
-    g["w2"] = _wgrad(dyb, a)
+    g["w2"] = _wgrad(dyb, a, w2_s)
     dh2 = _dgrad(dz, w1_s)
-    g["w1"] = _wgrad(dz, h2)
+    g["w1"] = _wgrad(dz, h2, w1_s)
     nd = pd == 0.0
     dy, dyb1 = ops.layernorm_bwd(dh2, y, mu2, rs2, ln2w, g["ln2w"], g["ln2b"], dres=dy2, want_bf16=True,
                                  dxsum=g["bp"] if nd else None, dressum=g["b2"] if nd else None)
@@ -511,7 +527,7 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
         ops.colsum(dyb, out=g["b2"], accumulate=True)
         dyb1 = _masked(dyb1, pd, seeds[1])
         ops.colsum(dyb1, out=g["bp"], accumulate=True)
-    g["wp"] = _wgrad(dyb1, oc)
+    g["wp"] = _wgrad(dyb1, oc, wp_s)
     if lowrank:
         # d(attention output) in fp32: it meets Wv_h as an fp32 row (xvit_head_rows)
         doc = torch.empty(B, d, dtype=torch.float32, device=xi.device)
@@ -526,8 +542,8 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
         T = torch.empty(B, 16, d, dtype=torch.float32, device=xi.device)
         ops.gemm(ops.TN, dsb, hn3, T)                                              # T[b, h] = sum_n ds hn[b, n]
         dq, _ = ops.head_cols(T, wk, H)                                            # dq_h = Wk_h T_h  (the bk term carries sum_n ds = 0)
-        g["wk"] = ops.head_wgrad(qf, T, H)
-        g["wv"] = ops.head_wgrad(doc, S, H, row_scale=rz)
+        g["wk"] = ops.head_wgrad(qf, T, H, out=_grad_out(wk, (d, d), xi.device))
+        g["wv"] = ops.head_wgrad(doc, S, H, row_scale=rz, out=_grad_out(wv, (d, d), xi.device))
         g["bv"] = ops.colsum(doc)
         g["bk"] = bk0                                                              # analytically zero: sum_n ds[n] = 0
         return _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d, dy)
@@ -555,7 +571,7 @@ def _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d,
     dhn0 = dhn.reshape(B, N * d)[:, :d]
     dhn0.copy_(dhn0.float() + dhq.float())                  # B rows: merge the two paths into the CLS rows
     hn0 = hn.reshape(B, N * d)[:, :d]
-    g["wq"] = _wgrad(dqb, hn0)
+    g["wq"] = _wgrad(dqb, hn0, wq_s)
     g["bq"] = ops.colsum(dq)
     dcat, _ = ops.layernorm_bwd(dhn, xj, mu, rs, ln1w, g["ln1w"], g["ln1b"], x_alt=xi, seq_len=N)
     _join_wgrads(xi.device)
@@ -655,7 +671,7 @@ class PatchEmbedFn(Function):
         if p > 0.0:                       # self.dropout on the embedded tokens (model_cross.py:198)
             ops.dropout(x, p, seed, out=x)
         ctx.meta = (M, Bn, N, d, p, seed, patch if fused else None)
-        ctx.save_for_backward(patches)     # fused: the volume tensor itself
+        ctx.save_for_backward(patches, w_s)     # fused: the volume tensor itself
         if concat:
             return x.reshape(Bn, N, d)
         # one output per modality (views of one buffer): slicing a stacked [M, B, N, d] output in the caller would cost
@@ -665,7 +681,7 @@ class PatchEmbedFn(Function):
     @staticmethod
     def backward(ctx, *dxs):
         M, Bn, N, d, p, seed, fused_patch = ctx.meta
-        (patches,) = ctx.saved_tensors
+        patches, w_s = ctx.saved_tensors
         dev = patches.device
         dpos = torch.zeros(N, d, dtype=torch.float32, device=dev)
         dcls = torch.zeros(d, dtype=torch.float32, device=dev)
@@ -683,9 +699,9 @@ class PatchEmbedFn(Function):
                 ops.cast_bf16(g2, dxb[m * Bn * N:(m + 1) * Bn * N])
                 ops.embed_bwd(g2, dpos, dcls, Bn, N, d)      # accumulates into dpos / dcls
         if fused_patch is not None:
-            dW = ops.patch_embed_wgrad(patches, fused_patch, dxb, cls_rows=1)     # contraction over the patch rows only
+            dW = ops.patch_embed_wgrad(patches, fused_patch, dxb, cls_rows=1, out=_grad_out(w_s, tuple(w_s.shape), dev))     # contraction over the patch rows only
         else:
-            dW = _wgrad(dxb, patches)        # the zero CLS rows of `patches` drop the CLS-row gradients
+            dW = _wgrad(dxb, patches, w_s)   # the zero CLS rows of `patches` drop the CLS-row gradients
         db = ops.colsum(dpos[1:])            # bias reaches the P patch rows of every sample
         _join_wgrads(dev)
         return None, dW, db, dcls.reshape(1, 1, d), dpos.reshape(1, N, d), None, None, None
@@ -727,7 +743,7 @@ class HeadFn(Function):
         dW3, db3 = torch.zeros_like(w3), _zeros(w3.shape[0], dl)
         dz = _masked(ops.small_linear_bwd(dl, a, w3.detach(), dW3, db3, z=z), p, seeds[0])
         dh = _dgrad(dz, w0_s)
-        dW0 = _wgrad(dz, h)
+        dW0 = _wgrad(dz, h, w0_s)
         db0 = ops.colsum(dz)
         dg, dbeta = _zeros(d, dl), _zeros(d, dl)
         dxc, _ = ops.layernorm_bwd(dh, x2, mu, rs, lnw, dg, dbeta)

@@ -32,7 +32,12 @@ from . import functional as XF
 
 
 class GraphedStep:
-    def __init__(self, model, img, labels, warmup: int = 3):
+    """reducer (xvit.ddp.BucketedGradReducer, optional): data-parallel runs.  The reducer's bucket views become the gradient buffers
+    (weight-gradient kernels write into them, functional.GRAD_SINK) and its bucket all-reduces are captured INTO the graph, each
+    forked onto the comm stream behind its last gradient and joined before the graph ends — the reference's setting (8 volume
+    pairs per GPU under DDP, main_mist.py:206, 211-218) is exactly where only the graph removes the host bound."""
+
+    def __init__(self, model, img, labels, warmup: int = 3, reducer=None):
         if not img.is_cuda:
             raise RuntimeError("GraphedStep needs GPU tensors")
         for m in model.modules():
@@ -48,6 +53,12 @@ class GraphedStep:
         self._named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         self.params = [p for _, p in self._named]
         self._alias = {n: p.detach().requires_grad_() for n, p in self._named}
+        self.reducer = reducer
+        self._sink = reducer.grad_sink(model) if reducer is not None else None
+        if reducer is not None:
+            with torch.no_grad():
+                for b in reducer.buckets:          # a parameter the step never reaches keeps reducing these zeros (eager mode: zeros_like)
+                    b.flat.zero_()
         self.img = img.clone()
         self.labels = labels.clone()
         self._prev_streams = os.environ.get("XVIT_STREAMS")
@@ -70,6 +81,9 @@ class GraphedStep:
                     self.logits, self.loss = self._eager(zero=False)
             finally:
                 XF.release_capture_keep()         # tensors that crossed streams were kept alive up to here (functional.keep)
+            if reducer is not None:
+                for p in self.params:              # from now on p.grad IS the bucket view the graph's collectives reduce in place
+                    p.grad = reducer._view_of[id(p)]
             # the graph holds raw addresses: remember where the parameters (and the flat weight buffers) live
             self._ptrs = [p.data_ptr() for p in self.params]
             self._flat = getattr(model, "_flat", None)
@@ -87,10 +101,25 @@ class GraphedStep:
             for p in self.params:
                 p.grad = None
         XF.SHADOWS.force = True                # the captured step always re-casts the weights (they change every step)
-        logits, loss = torch.func.functional_call(self.model, self._alias, (self.img, self.labels))
-        grads = torch.autograd.grad(loss, [self._alias[n] for n, _ in self._named], allow_unused=True)   # see the module docstring
-        for p, g in zip(self.params, grads):
-            p.grad = g
+        red = self.reducer
+        if red is None:
+            logits, loss = torch.func.functional_call(self.model, self._alias, (self.img, self.labels))
+            grads = torch.autograd.grad(loss, [self._alias[n] for n, _ in self._named], allow_unused=True)   # see the module docstring
+            for p, g in zip(self.params, grads):
+                p.grad = g
+            return logits.detach(), loss.detach()
+        prev_sink, XF.GRAD_SINK = XF.GRAD_SINK, self._sink
+        handles = red.attach_leaves([(p, self._alias[n]) for n, p in self._named])
+        red.set_graph_mode(True)
+        try:
+            logits, loss = torch.func.functional_call(self.model, self._alias, (self.img, self.labels))
+            torch.autograd.grad(loss, [self._alias[n] for n, _ in self._named], allow_unused=True)   # the hooks move / count the gradients
+            red.finish()                       # unused parameters' buckets, then the capture stream waits for every collective
+        finally:
+            red.set_graph_mode(False)
+            XF.GRAD_SINK = prev_sink
+            for h in handles:
+                h.remove()
         return logits.detach(), loss.detach()
 
     def __call__(self, img=None, labels=None):

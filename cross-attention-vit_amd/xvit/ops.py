@@ -377,11 +377,12 @@ def head_cols(t, W, H, row_scale=None, bias=None, want_bf16=False):
     return out, ob
 
 
-def head_wgrad(x, t, H, row_scale=None):
+def head_wgrad(x, t, H, row_scale=None, out=None):
     """dW[64h+e, :] = sum_b x[b, 64h+e] row_scale[b, h] t[b, h, :] (xvit_head_wgrad) -> fp32 [d, d]."""
     B, d = x.shape
     assert x.dtype == torch.float32 and t.dtype == torch.float32 and t.stride(2) == 1 and t.shape[0] == B and t.shape[2] == d
-    dW = torch.empty(d, d, dtype=torch.float32, device=x.device)
+    dW = out if out is not None else torch.empty(d, d, dtype=torch.float32, device=x.device)
+    assert dW.shape == (d, d) and dW.is_contiguous() and dW.dtype == torch.float32
     _run("head_linear", 2.0 * B * d * 64, "flop",
          lambda: _lib.load().xvit_head_wgrad(_ptr(x), _rows2d(x), _ptr(t), t.stride(0), t.stride(1), _ptr(row_scale), row_scale.stride(0) if row_scale is not None else 0,
                                              _ptr(dW), d, B, H, d, _stream()), "xvit_head_wgrad")
@@ -477,7 +478,7 @@ def patch_embed_fwd(img, patch, w_b, bias, pos, cls_rows=1):
     return x
 
 
-def patch_embed_wgrad(img, patch, dx_b, cls_rows=1):
+def patch_embed_wgrad(img, patch, dx_b, cls_rows=1, out=None):
     """dW [d, pd] fp32 = sum over patch rows of dx[row]^T patch(row); dx_b: bf16 [M*B*(cls_rows + P), d]."""
     g = _patch_geom(img, patch, cls_rows)
     B, M, _, D, H, W = img.shape
@@ -486,7 +487,8 @@ def patch_embed_wgrad(img, patch, dx_b, cls_rows=1):
     assert dx_b.dtype == torch.bfloat16 and dx_b.shape[0] == M * B * (cls_rows + P) and dx_b.is_contiguous()
     need = _lib.load().xvit_patch_embed_wgrad_workspace_bytes(C.byref(g), d)
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=img.device)
-    dW = torch.empty(d, pd, dtype=torch.float32, device=img.device)
+    dW = out if out is not None else torch.empty(d, pd, dtype=torch.float32, device=img.device)
+    assert dW.shape == (d, pd) and dW.is_contiguous() and dW.dtype == torch.float32
     _run("gemm_big_tn+splitk", 2.0 * M * B * P * d * pd, "flop",
          lambda: _lib.load().xvit_patch_embed_wgrad(_ptr(img), C.byref(g), _ptr(dx_b), dx_b.stride(0), _ptr(dW), dW.stride(0), d, _ptr(ws), need, _stream()),
          "xvit_patch_embed_wgrad")

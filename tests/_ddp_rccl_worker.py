@@ -43,6 +43,23 @@ def main():
         opt.step()
     torch.cuda.synchronize()
     torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, os.path.join(out_dir, f"p{rank}.pt"))
+    # the captured step with the collectives inside the graph: its reduced gradients must be the eager reducer's, on every rank
+    from xvit.graph import GraphedStep
+    red.zero_grad()
+    _, loss = model(img, labels)
+    loss.backward()
+    red.finish()
+    torch.cuda.synchronize()
+    eager = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    step = GraphedStep(model, img, labels, reducer=red)
+    step()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, p in model.named_parameters():
+        ref = eager[k]
+        if float(ref.abs().max()) > 1e-6:
+            worst = max(worst, float((p.grad - ref).norm() / ref.norm()))
+    torch.save({"worst": worst, "grads": {k: p.grad.detach().cpu().clone() for k, p in model.named_parameters()}}, os.path.join(out_dir, f"graph{rank}.pt"))
     if rank == 0:
         print(f"rccl ranks: {dist.get_world_size()} buckets: {len(red.buckets)}", flush=True)
     dist.destroy_process_group()

@@ -73,6 +73,59 @@ def test_reducer_orders_behind_every_branch_stream_one_rank_rccl(monkeypatch):
         dist.destroy_process_group()
 
 
+def test_graphed_step_with_reducer_one_rank_rccl(monkeypatch):
+    """The captured step and the reducer together (the reference's DDP setting at 8 volume pairs per GPU is host-bound without the
+    graph): weight gradients are written straight into the bucket views, the bucket all-reduces are nodes of the captured graph.
+    1-rank RCCL group on this box: replayed + reduced gradients == eager gradients without a reducer (bit for bit for the weight
+    matrices), p.grad ARE the bucket views, new inputs are followed, and the eager reducer path with the gradient sink agrees too."""
+    import torch.distributed as dist
+    import xvit
+    import xvit.functional as XF
+    from xvit.ddp import BucketedGradReducer
+    from xvit.graph import GraphedStep
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    cfg = R.make_config("small")
+    model = xvit.ModelCross(cfg).to(dev())
+    model.load_state_dict(R.make_state_dict(cfg, seed=0))
+    model.train()
+    ins = [tuple(t.to(dev()) for t in R.make_inputs(cfg, 6, seed=s)) for s in (2, 7)]
+    refs = [_grads(model, *i) for i in ins]
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    try:
+        red = BucketedGradReducer(list(model.parameters()), bucket_bytes=128 << 10)
+        # eager + gradient sink: no pack copy for the weight matrices
+        XF.GRAD_SINK = red.grad_sink(model)
+        try:
+            got = _grads(model, *ins[0], red)
+        finally:
+            XF.GRAD_SINK = None
+        sunk = 0
+        for k, p in model.named_parameters():
+            assert p.grad.data_ptr() == red._view_of[id(p)].data_ptr(), k
+            if p.dim() == 2:
+                assert torch.equal(got[k], refs[0][k]), k
+                sunk += 1
+            else:
+                assert rel(got[k], refs[0][k]) < 1e-5 or float(refs[0][k].abs().max()) < 1e-6, k
+        assert sunk > 20
+        # captured step + captured collectives
+        step = GraphedStep(model, *ins[0], reducer=red)
+        for which in (0, 1, 0):
+            step(*ins[which])
+            torch.cuda.synchronize()
+            for k, p in model.named_parameters():
+                assert p.grad.data_ptr() == red._view_of[id(p)].data_ptr(), k
+                ref = refs[which][k]
+                if p.dim() == 2:
+                    assert torch.equal(p.grad, ref), (which, k)
+                else:
+                    assert rel(p.grad, ref) < 1e-5 or float(ref.abs().max()) < 1e-6, (which, k)
+        red.remove()
+    finally:
+        dist.destroy_process_group()
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (the gpurun box has one; the driver's 8-GPU node runs it)")
 def test_model_cross_two_rccl_ranks(tmp_path):
     import xvit
@@ -98,3 +151,7 @@ def test_model_cross_two_rccl_ranks(tmp_path):
         assert rel(g0[k], ref[k].cpu()) < 2e-3 or float(ref[k].abs().max()) < 1e-6, k   # mean of shard gradients == global-batch gradient (bf16 operands: per-shard rounding differs)
     for k in p0:
         assert torch.equal(p0[k], p1[k]), k                                    # replicas stay in lock-step through 3 Adam steps
+    q0, q1 = torch.load(tmp_path / "graph0.pt"), torch.load(tmp_path / "graph1.pt")
+    assert q0["worst"] < 1e-5 and q1["worst"] < 1e-5, (q0["worst"], q1["worst"])   # captured step + captured collectives == eager reducer
+    for k in q0["grads"]:
+        assert torch.equal(q0["grads"][k], q1["grads"][k]), k
