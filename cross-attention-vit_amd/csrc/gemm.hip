@@ -44,6 +44,7 @@ struct GemmParams {
     int nb;                // samples are ordered [modality][batch]: s -> modality s / nb, batch s % nb
     int64_t sBt, sMd;      // element strides of batch and modality in the volume tensor
     uint32_t vol_bytes;
+    uint32_t m_pcount, m_dn, m_wn, m_nb;   // floor(2^32 / divisor): mode 3 divides by these every K-step (fast_div)
   } g;
 };
 
@@ -60,6 +61,30 @@ __device__ __forceinline__ uint32_t gather_patch_origin(const GemmParams::PatchG
 __device__ __forceinline__ uint32_t gather_sample_origin(const GemmParams::PatchGather& g, int s) {
   const int mod = s / g.nb, b = s - mod * g.nb;
   return (uint32_t)(b * g.sBt + mod * g.sMd);
+}
+
+// n / d for any 32-bit n with m = floor(2^32 / d): the estimate is at most one short (n m / 2^32 > n / d - 1), one correction step makes it exact
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, uint32_t d, uint32_t m, uint32_t& rem) {
+  uint32_t q = __umulhi(n, m);
+  rem = n - q * d;
+  if (rem >= d) { ++q; rem -= d; }
+  return q;
+}
+// mode 3 (weight gradient, ANY patch grid — e.g. 15 patches per axis at configs[2]'s 240^3 volumes, where 64 consecutive tokens are
+// neither whole d-columns nor inside one sample): the contraction index is the running patch-token count T over all samples; every
+// K-step each lane places its k-rows itself.  T -> (sample, token q) -> dx row (CLS rows skipped) and volume offset of the patch.
+struct GatherTok { uint32_t row, vol; bool ok; };
+__device__ __forceinline__ GatherTok gather_token(const GemmParams::PatchGather& g, uint32_t T, uint32_t total) {
+  GatherTok o;
+  o.ok = T < total;
+  uint32_t q, b, d, w;
+  const uint32_t smp = fast_div(o.ok ? T : 0u, (uint32_t)g.pcount, g.m_pcount, q);
+  const uint32_t mod = fast_div(smp, (uint32_t)g.nb, g.m_nb, b);
+  const uint32_t t = fast_div(q, (uint32_t)g.Dn, g.m_dn, d);
+  const uint32_t h = fast_div(t, (uint32_t)g.Wn, g.m_wn, w);
+  o.row = smp * (uint32_t)g.ntok + (uint32_t)g.cls + q;
+  o.vol = (uint32_t)(b * g.sBt + mod * g.sMd) + d * (uint32_t)(g.dp * g.Sz) + h * (uint32_t)(g.hp * g.Sy) + w * (uint32_t)g.wp;
+  return o;
 }
 
 // compile-time activation codes of the wide epilogue kernels for aux_mode 1 (the public codes + p.aux_deriv everywhere else)
@@ -410,6 +435,16 @@ struct BigLoader {
       voff[j] = e < N ? 2u * ((uint32_t)((tok % g.Dn) * g.dp * g.Sz + (tok / g.Dn) * g.wp) + gather_elem_off(g, e)) : GATHER_OOB;
     }
     kstep = 0;
+  }
+  // mode 3: k-row kr of K-step ktg is patch token T = 64 ktg + kr.  KS operand A = dx (row = token row, this lane's 16-byte column chunk),
+  // KS operand B = the volume (this lane's feature chunk of the token's patch).  `fixed` = the lane's part that does not move.
+  __device__ __forceinline__ void place_tokens(const GemmParams::PatchGather& g, int ktg, uint32_t total, int64_t ld, bool volume, const uint32_t (&fixed)[4], int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int krow = (wave * 4 + j) * 2 + (lane >> 5);
+      const GatherTok t = gather_token(g, (uint32_t)ktg * 64u + (uint32_t)krow, total);
+      voff[j] = !t.ok || fixed[j] == GATHER_OOB ? GATHER_OOB : (volume ? 2u * t.vol + fixed[j] : t.row * (uint32_t)(ld * 2) + fixed[j]);
+    }
   }
   __device__ __forceinline__ void issue_at(XVIT_LDS char* image, int wave, uint32_t soff) const {
 #pragma unroll
@@ -982,21 +1017,37 @@ __global__ __launch_bounds__(512, 2) void gemm_big_kernel(const GemmParams p) {
   {
     const bf16* Ab = p.A + batch * p.sA;
     if constexpr (GATHER == 1) la.init_gather_rows(p.g, Ab, m0, p.M, wave, lane);
-    else if constexpr (GATHER == 2) {   // dY rows are re-indexed per K-step (CLS rows skipped): base = row 0, K-step offsets from gather_soff_wgrad
+    else if constexpr (GATHER == 2 || GATHER == 3) {   // dY rows are re-indexed per K-step (CLS rows skipped): base = row 0, K-step offsets from gather_soff_wgrad
       const int64_t rows = (int64_t)(p.K / p.g.pcount) * p.g.ntok;
-      la.init(Ab + m0, ((rows - 1) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane, &p.g);
+      la.init(Ab + m0, ((rows - 1) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane, GATHER == 2 ? &p.g : nullptr);
     } else if (A_KS) la.init(Ab + (int64_t)k_begin * p.lda + m0, ((int64_t)(k_end - 1 - k_begin) * p.lda + (p.M - m0)) * 2, p.lda, wave, lane);
     else la.init(Ab + (int64_t)m0 * p.lda + k_begin, ((int64_t)(p.M - 1 - m0) * p.lda + (k_end - k_begin)) * 2, p.lda, wave, lane);
     const bf16* Bb = p.B + batch * p.sB;
-    if constexpr (GATHER == 2) lb.init_gather_ks(p.g, Bb, n0, p.N, wave, lane);
+    if constexpr (GATHER == 2 || GATHER == 3) lb.init_gather_ks(p.g, Bb, n0, p.N, wave, lane);
     else if (B_KS) lb.init(Bb + (int64_t)k_begin * p.ldb + n0, ((int64_t)(k_end - 1 - k_begin) * p.ldb + (p.N - n0)) * 2, p.ldb, wave, lane);
     else lb.init(Bb + (int64_t)n0 * p.ldb + k_begin, ((int64_t)(p.N - 1 - n0) * p.ldb + (k_end - k_begin)) * 2, p.ldb, wave, lane);
   }
   // byte offsets of K-step kt (relative to this split's first) for the two loaders
   const int ktg0 = k_begin / BK;
+  uint32_t fix_a[4], fix_b[4];       // mode 3: the lanes' fixed parts (column chunk of dx, feature chunk of the patch); the token part is placed per K-step
+  if constexpr (GATHER == 3) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int krow = (wave * 4 + j) * 2 + (lane >> 5);
+      const int chunk = (lane & 31) ^ swz_ks(krow);
+      fix_a[j] = m0 + chunk * 8 < p.M ? (uint32_t)(chunk * 16) : GATHER_OOB;
+      const int e = n0 + (chunk << 3);
+      fix_b[j] = e < p.N ? 2u * gather_elem_off(p.g, e) : GATHER_OOB;
+    }
+  }
   auto step_off = [&](int kt, uint32_t& oa, uint32_t& ob) {
     if constexpr (GATHER == 1) { oa = gather_soff_rows(p.g, ktg0 + kt); ob = (uint32_t)kt * lb.kstep; }
     else if constexpr (GATHER == 2) { GatherStep o; o = gather_soff_wgrad(p.g, ktg0 + kt, p.lda); oa = o.a; ob = o.b; }
+    else if constexpr (GATHER == 3) {
+      la.place_tokens(p.g, ktg0 + kt, (uint32_t)p.K, p.lda, false, fix_a, wave, lane);
+      lb.place_tokens(p.g, ktg0 + kt, (uint32_t)p.K, 0, true, fix_b, wave, lane);
+      oa = ob = 0u;
+    }
     else { oa = (uint32_t)kt * la.kstep; ob = (uint32_t)kt * lb.kstep; }
   };
   BigFrag<A_KS, 8> fa;
@@ -1216,13 +1267,20 @@ extern "C" int xvit_patch_embed_supported(const xvit_patch_geom* g, int d) {
   const int Dn = g->D / g->dp, Hn = g->H / g->hp, Wn = g->W / g->wp;
   const int64_t pd = (int64_t)g->dp * g->hp * g->wp, pcount = (int64_t)Dn * Hn * Wn;
   if (g->wp % 8 || 64 % g->wp || (g->hp * g->wp) % 64) return 0;          // a K-step = whole runs of one (p1) slab
-  if (64 % Dn || (Dn * Wn) % 64) return 0;                                  // 64 consecutive tokens = whole d-columns of one h
+  // (any patch grid: where 64 consecutive tokens are not whole d-columns of one h — 64 % Dn, (Dn Wn) % 64 — the weight gradient
+  // places its k-rows per K-step, pe_aligned() below)
   if (pd % 256 || d % 256 || d < 256) return 0;                            // full 256-wide tiles on both outputs
   const int64_t rows = pe_rows(g);
   if (rows < 2048) return 0;                                               // small problems: the 128x128 kernels on a stored patch matrix
   if ((int64_t)g->B * g->M * g->D * g->H * g->W * 2 >= (1ll << 31)) return 0;
   if (rows * d * 4 >= (1ll << 31) || pcount > (1 << 24)) return 0;
   return 1;
+}
+
+// 64 consecutive patch tokens of a sample are whole d-columns of one h-row: the weight gradient's K-step offsets are wave-uniform (mode 2)
+static bool pe_aligned(const xvit_patch_geom* g) {
+  const int Dn = g->D / g->dp, Wn = g->W / g->wp;
+  return 64 % Dn == 0 && (Dn * Wn) % 64 == 0;
 }
 
 static void pe_fill(GemmParams& p, const xvit_patch_geom* g, int mode) {
@@ -1235,6 +1293,8 @@ static void pe_fill(GemmParams& p, const xvit_patch_geom* g, int mode) {
   p.g.nb = g->B;
   p.g.sMd = (int64_t)g->D * g->H * g->W; p.g.sBt = p.g.sMd * g->M;
   p.g.vol_bytes = (uint32_t)((int64_t)g->B * g->M * g->D * g->H * g->W * 2);
+  auto magic = [](int d) { return d <= 1 ? 0xFFFFFFFFu : (uint32_t)((1ull << 32) / (uint64_t)d); };
+  p.g.m_pcount = magic(p.g.pcount); p.g.m_dn = magic(p.g.Dn); p.g.m_wn = magic(p.g.Wn); p.g.m_nb = magic(p.g.nb);
 }
 
 static void pe_defaults(GemmParams& p) {
@@ -1251,6 +1311,7 @@ static void pe_attrs() {
   std::call_once(once, [] {
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, -1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, -1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, -1, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS);
   });
 }
 
@@ -1304,19 +1365,21 @@ extern "C" int xvit_patch_embed_wgrad(const void* img, const xvit_patch_geom* g,
                (long long)need, (long long)workspace_bytes);
   GemmParams p;
   pe_defaults(p);
-  pe_fill(p, g, 2);
+  const bool aligned = pe_aligned(g);
+  pe_fill(p, g, aligned ? 2 : 3);
   p.A = (const bf16*)dx; p.B = (const bf16*)img; p.C = dW;
   p.lda = lddx; p.ldc = lddw;
   p.M = d; p.N = (int)pd;
   p.K = (int)((int64_t)g->M * g->B * p.g.pcount);          // contraction over the patch rows; CLS rows carry no patch
   p.split_k = pe_wgrad_split(g, d);
-  const int ktiles = p.K / BK;
+  const int ktiles = (p.K + BK - 1) / BK;                     // mode 3: K need not be a multiple of 64 (tokens past it are zero rows)
   p.k_per_split = ((ktiles + p.split_k - 1) / p.split_k) * BK;
   p.slab = need > 0 ? (float*)workspace : nullptr;
   p.ntm = (p.M + TBM - 1) / TBM; p.ntn = (p.N + TBN - 1) / TBN; p.ncg = p.ntn;
   pe_attrs();
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL((gemm_big_kernel<true, true, -1, 2>), dim3(p.ntm * p.ntn, 1, p.split_k), dim3(512), T_LDS, s, p);
+  if (aligned) hipLaunchKernelGGL((gemm_big_kernel<true, true, -1, 2>), dim3(p.ntm * p.ntn, 1, p.split_k), dim3(512), T_LDS, s, p);
+  else hipLaunchKernelGGL((gemm_big_kernel<true, true, -1, 3>), dim3(p.ntm * p.ntn, 1, p.split_k), dim3(512), T_LDS, s, p);
   if (p.slab) {
     const int64_t work = (int64_t)p.M * (p.N / 4);
     const int gsz = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);

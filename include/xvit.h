@@ -241,8 +241,11 @@ int xvit_patchify(const void* img, int img_dtype, void* patches_bf16, int B, int
  * bias + pos[0] and are overwritten by xvit_cls_row_fwd, exactly as with a zero CLS row in a stored patch matrix.
  * xvit_patch_embed_wgrad: dW[d, pd] = sum over patch rows of dx[row, :]^T patch(row) (CLS rows of dx are skipped), fp32,
  * split over the contraction into the caller's workspace and summed in a fixed order (deterministic).
- * xvit_patch_embed_supported: 1 when the geometry fits the fused kernels (wp in {8,16,32,64}, hp*wp % 64 == 0, 64 % (D/dp) == 0,
- * (D/dp)*(W/wp) % 64 == 0, pd and d multiples of 256, >= 2048 rows, volume < 2 GiB); otherwise use xvit_patchify + xvit_gemm.
+ * xvit_patch_embed_supported: 1 when the geometry fits the fused kernels (wp in {8,16,32,64}, hp*wp % 64 == 0, pd and d multiples of
+ * 256, >= 2048 rows, volume < 2 GiB); otherwise use xvit_patchify + xvit_gemm.  ANY patch grid qualifies: where 64 consecutive tokens
+ * are whole d-columns of one h-row (64 % (D/dp) == 0 and (D/dp)*(W/wp) % 64 == 0: 128^3 volumes) the weight gradient's K-step offsets
+ * are wave-uniform; elsewhere (15 patches per axis at the 240^3 UCSF-PDGM shape, dataset_ucsf.py:84-88) every lane places its k-rows
+ * per K-step from the running token count (three multiply-high divisions), K-steps may straddle samples.
  * ---------------------------------------------------------------------------------------- */
 typedef struct xvit_patch_geom {
   int32_t B, M;          /* img [B, M, 1, D, H, W] */

@@ -63,7 +63,8 @@ def test_patch_embed_geometry_predicate_and_workspaces():
     ok = lambda g, d: lib.xvit_patch_embed_supported(C.byref(g), d)   # noqa: E731
     assert ok(geom(126, 2, (128, 128, 128), (16, 16, 16)), 768) == 1          # configs[1]
     assert ok(geom(8, 2, (128, 128, 128), (8, 8, 8)), 768) == 1               # configs[4]
-    assert ok(geom(8, 4, (240, 240, 240), (16, 16, 16)), 768) == 0            # configs[2]: 15 patches per axis (64 % 15 != 0)
+    assert ok(geom(2, 4, (240, 240, 240), (16, 16, 16)), 768) == 1            # configs[2]: 15 patches per axis (the weight gradient places k-rows per K-step)
+    assert ok(geom(20, 4, (240, 240, 240), (16, 16, 16)), 768) == 0           # ... this volume tensor is beyond 2 GiB of bf16
     assert ok(geom(1, 1, (128, 128, 128), (16, 16, 16)), 768) == 0            # 513 rows: small-tile path
     assert ok(geom(126, 2, (128, 128, 128), (16, 16, 16)), 192) == 0          # d not a multiple of 256
     assert ok(geom(126, 2, (128, 128, 128), (16, 16, 4)), 768) == 0           # 8-byte runs

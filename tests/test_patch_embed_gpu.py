@@ -18,6 +18,10 @@ GEOMS = [
     pytest.param(5, 1, (64, 64, 64), (8, 8, 8), 256, id="64cube-8cube"),
     pytest.param(3, 2, (128, 64, 128), (16, 8, 16), 512, id="non-cubic"),
     pytest.param(6, 3, (128, 32, 256), (16, 16, 32), 256, id="wide-runs"),
+    # patch grids where 64 consecutive tokens are NOT whole d-columns of one h-row: the weight gradient places its k-rows per K-step
+    pytest.param(1, 2, (240, 240, 240), (16, 16, 16), 768, id="configs2-240cube-15-per-axis"),   # configs[2]: 3375 patches (dataset_ucsf.py:84-88)
+    pytest.param(20, 1, (80, 48, 112), (16, 16, 16), 256, id="odd-grid-5x3x7"),                  # 105 patches per sample: K-steps straddle samples
+    pytest.param(2, 3, (96, 160, 48), (8, 16, 16), 512, id="odd-grid-12x10x3"),
 ]
 
 
