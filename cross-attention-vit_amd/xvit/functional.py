@@ -212,13 +212,18 @@ def _dp(p, seed):
 # ------------------------------------------------------------------------------------------
 
 
+# depth cap of the split: with 9 tiles (a d x d gradient) 16 splits fill 144 of the 256 CUs, 28 fill 252: 106 -> 89 us at K = 64638
+# (tools/gemm_model_bench.py, XVIT_WGRAD_SPLIT_CAP=16 / 20 / 24 / 28: 106.2 / 94.6 / 90.8 / 88.6 us)
+_WGRAD_SPLIT_CAP = int(os.environ.get("XVIT_WGRAD_SPLIT_CAP", "28"))
+
+
 def _wgrad_split(m, n, k):
     """Split-K factor for a TN wgrad: enough workgroups to fill 256 CUs, but >= 16 K-steps each on the 256x256 tiles (at the
     reference's batch 8 — 64 K-steps in all — 16 splits of 4 steps cost 29 us per d x d gradient where 4 of 16 cost 21: prologue,
     epilogue and slab traffic per split; tools/gemm_model_bench.py 8)."""
     if m >= 256 and n >= 256:   # 256x256 tiles, one block per CU
         tiles = ((m + 255) // 256) * ((n + 255) // 256)
-        return max(1, min(256 // max(tiles, 1), ((k + 63) // 64) // 16, 16))
+        return max(1, min(256 // max(tiles, 1), ((k + 63) // 64) // 16, _WGRAD_SPLIT_CAP))
     tiles = ((m + 127) // 128) * ((n + 127) // 128)
     return max(1, min(512 // max(tiles, 1), ((k + 63) // 64) // 8, 32))
 
