@@ -109,19 +109,19 @@ __global__ __launch_bounds__(64) void head_wgrad_kernel(const HeadParams p) {
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-  for (int k0 = 0; k0 < p.B; k0 += 8) {
-    float a[4], w[4];
+  for (int k0 = 0; k0 < p.B; k0 += 32) {     // four 8-deep steps (48 loads) in flight before their MFMAs: the loop is latency-, not rate-bound
+    float a[16], w[16], sc[16];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int b = k0 + 4 * hl + e;
+    for (int i = 0; i < 16; ++i) {
+      const int b = k0 + 8 * (i >> 2) + 4 * hl + (i & 3);
       const bool in = b < p.B;
       const int bc = in ? b : 0;
-      const float s = in ? (p.rs ? p.rs[(int64_t)bc * p.rs_ld + h] : 1.f) : 0.f;
-      a[e] = p.x[(int64_t)bc * p.ldx + xcol] * s;
-      w[e] = tp[(int64_t)bc * p.t_sb];
+      sc[i] = in ? (p.rs ? p.rs[(int64_t)bc * p.rs_ld + h] : 1.f) : 0.f;
+      a[i] = p.x[(int64_t)bc * p.ldx + xcol];
+      w[i] = tp[(int64_t)bc * p.t_sb];
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], w[e], acc, 0, 0, 0);
+    for (int i = 0; i < 16; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i] * sc[i], w[i], acc, 0, 0, 0);
   }
   const int col = tn * 32 + r;
 #pragma unroll
@@ -134,27 +134,31 @@ __global__ __launch_bounds__(64) void head_wgrad_kernel(const HeadParams p) {
 // softmax over the tokens of one (sample, head) column of s [B, N, ld] (fp32 scores, scale folded in here):
 //   e[b, n, h] = exp(scale (s - max_n s)) as bf16 (the weights of the row-sum GEMM; columns h >= H of the padded rows are zeroed),
 //   rz[b, h] = 1 / sum_n e (the sum of the ROUNDED weights, so that the weights the GEMM sees sum to one).   grid (B), block 256
-__global__ __launch_bounds__(256) void cls_softmax_kernel(const float* __restrict__ s, int64_t ld, bf16* __restrict__ e, int64_t lde, float* __restrict__ rz,
+constexpr int SM_T = 1024;   // 64 rows x 16 columns per pass: the kernels are chains of dependent row passes, so more rows per pass = fewer trips
+__global__ __launch_bounds__(SM_T) void cls_softmax_kernel(const float* __restrict__ s, int64_t ld, bf16* __restrict__ e, int64_t lde, float* __restrict__ rz,
                                                            int H, int N, float scale) {
-  __shared__ float red[4][32];
+  constexpr int NW = SM_T / 64, RP = SM_T / 16;
+  __shared__ float red[NW][16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* sb = s + (int64_t)b * N * ld;
   bf16* eb = e + (int64_t)b * N * lde;
-  // thread t owns column t % 16 of rows t / 16, t / 16 + 16, ...: a row's 16 floats are one 64-byte segment
+  // thread t owns column t % 16 of rows t / 16, t / 16 + RP, ...: a row's 16 floats are one 64-byte segment
   const int col = tid & 15, r0 = tid >> 4;
   float mx = -INFINITY;
   if (col < H)
-    for (int n = r0; n < N; n += 16) mx = fmaxf(mx, sb[(int64_t)n * ld + col]);
-  // reduce over the 16 threads of a column: lanes with equal (lane & 15) inside a wave, then the 4 waves
+    for (int n = r0; n < N; n += RP) mx = fmaxf(mx, sb[(int64_t)n * ld + col]);
+  // reduce over the threads of a column: lanes with equal (lane & 15) inside a wave, then the waves (fixed order)
   mx = fmaxf(mx, __shfl_xor(mx, 16));
   mx = fmaxf(mx, __shfl_xor(mx, 32));
   if (lane < 16) red[wave][lane] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[0][col], red[1][col]), fmaxf(red[2][col], red[3][col]));
+  mx = red[0][col];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w][col]);
   __syncthreads();
   float sum = 0.f;
   const float c = scale * 1.4426950408889634f;
-  for (int n = r0; n < N; n += 16) {
+  for (int n = r0; n < N; n += RP) {
     bf16 w = f2bf(0.f);
     if (col < H) {
       w = f2bf(__builtin_amdgcn_exp2f((sb[(int64_t)n * ld + col] - mx) * c));
@@ -166,14 +170,20 @@ __global__ __launch_bounds__(256) void cls_softmax_kernel(const float* __restric
   sum += __shfl_xor(sum, 32);
   if (lane < 16) red[wave][lane] = sum;
   __syncthreads();
-  if (tid < H) rz[(int64_t)b * H + tid] = 1.0f / (((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid]);
+  if (tid < H) {
+    float t = red[0][tid];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red[w][tid];
+    rz[(int64_t)b * H + tid] = 1.0f / t;
+  }
 }
 
 // backward of that softmax: p = e rz, ds = scale p (dp - sum_n p dp) -> coef[b, n, 0 .. H) = ds, coef[b, n, H .. 2 H) = p (fp32, the input
 // of xvit_xattn_kv_dgrad) and ds_bf16[b, n, 0 .. ldb) (the weights of the row-sum GEMM that gives T; columns >= H zeroed)
-__global__ __launch_bounds__(256) void cls_softmax_bwd_kernel(const bf16* __restrict__ e, int64_t lde, const float* __restrict__ rz, const float* __restrict__ dp, int64_t ldp,
+__global__ __launch_bounds__(SM_T) void cls_softmax_bwd_kernel(const bf16* __restrict__ e, int64_t lde, const float* __restrict__ rz, const float* __restrict__ dp, int64_t ldp,
                                                                float* __restrict__ coef, bf16* __restrict__ dsb, int64_t ldb, int H, int N, float scale) {
-  __shared__ float red[4][32];
+  constexpr int NW = SM_T / 64, RP = SM_T / 16;
+  __shared__ float red[NW][16];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int col = tid & 15, r0 = tid >> 4;
   const bf16* eb = e + (int64_t)b * N * lde;
@@ -181,15 +191,17 @@ __global__ __launch_bounds__(256) void cls_softmax_bwd_kernel(const bf16* __rest
   const float z = col < H ? rz[(int64_t)b * H + col] : 0.f;
   float dsum = 0.f;
   if (col < H)
-    for (int n = r0; n < N; n += 16) dsum = fmaf(bf2f(eb[(int64_t)n * lde + col]) * z, dpb[(int64_t)n * ldp + col], dsum);
+    for (int n = r0; n < N; n += RP) dsum = fmaf(bf2f(eb[(int64_t)n * lde + col]) * z, dpb[(int64_t)n * ldp + col], dsum);
   dsum += __shfl_xor(dsum, 16);
   dsum += __shfl_xor(dsum, 32);
   if (lane < 16) red[wave][lane] = dsum;
   __syncthreads();
-  dsum = ((red[0][col] + red[1][col]) + red[2][col]) + red[3][col];
+  dsum = red[0][col];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) dsum += red[w][col];
   float* cb = coef + (int64_t)b * N * 2 * H;
   bf16* db = dsb + (int64_t)b * N * ldb;
-  for (int n = r0; n < N; n += 16) {
+  for (int n = r0; n < N; n += RP) {
     float ds = 0.f;
     if (col < H) {
       const float pr = bf2f(eb[(int64_t)n * lde + col]) * z;
@@ -255,7 +267,7 @@ extern "C" int xvit_head_wgrad(const float* x, int64_t ldx, const float* t, int6
 extern "C" int xvit_cls_softmax_fwd(const float* s, int64_t lds, void* e_bf16, int64_t lde, float* rz, int B, int H, int N, float scale, xvit_stream_t stream) {
   XVIT_REQUIRE(s && e_bf16 && rz, "xvit_cls_softmax_fwd: null pointer");
   XVIT_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 16 && lds >= H && lde >= H && lde <= 16, "xvit_cls_softmax_fwd: need H <= 16, lds >= H, H <= lde <= 16 (B=%d H=%d N=%d)", B, H, N);
-  hipLaunchKernelGGL(cls_softmax_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, s, lds, (bf16*)e_bf16, lde, rz, H, N, scale);
+  hipLaunchKernelGGL(cls_softmax_kernel, dim3(B), dim3(SM_T), 0, (hipStream_t)stream, s, lds, (bf16*)e_bf16, lde, rz, H, N, scale);
   return check_launch("xvit_cls_softmax_fwd");
 }
 
@@ -263,6 +275,6 @@ extern "C" int xvit_cls_softmax_bwd(const void* e_bf16, int64_t lde, const float
                                     int N, float scale, xvit_stream_t stream) {
   XVIT_REQUIRE(e_bf16 && rz && dp && coef && ds_bf16, "xvit_cls_softmax_bwd: null pointer");
   XVIT_REQUIRE(B > 0 && N > 0 && H > 0 && H <= 16 && lde >= H && ldp >= H && ldb >= H && ldb <= 16, "xvit_cls_softmax_bwd: need H <= 16, lde, ldp >= H, H <= ldb <= 16");
-  hipLaunchKernelGGL(cls_softmax_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (const bf16*)e_bf16, lde, rz, dp, ldp, coef, (bf16*)ds_bf16, ldb, H, N, scale);
+  hipLaunchKernelGGL(cls_softmax_bwd_kernel, dim3(B), dim3(SM_T), 0, (hipStream_t)stream, (const bf16*)e_bf16, lde, rz, dp, ldp, coef, (bf16*)ds_bf16, ldb, H, N, scale);
   return check_launch("xvit_cls_softmax_bwd");
 }

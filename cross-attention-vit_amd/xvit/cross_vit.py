@@ -156,19 +156,29 @@ class _FanOut(torch.autograd.Function):
     node — the pattern the branch fork already uses."""
 
     @staticmethod
-    def forward(ctx, x, n):
-        return tuple(x.view_as(x) for _ in range(n))
+    def forward(ctx, x, n, cls_first=False):
+        """cls_first: reader 0 (the modality's own fusion in a cls-only block, which uses nothing but the CLS rows) gets x[:, :1]."""
+        ctx.cls_first = cls_first
+        outs = [x.view_as(x) for _ in range(n)]
+        if cls_first:
+            outs[0] = x[:, :1]
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *gs):
-        gs = [g for g in gs if g is not None]
+        narrow = gs[0] if ctx.cls_first else None          # [B, 1, d]: joins the CLS rows only — no zero-filled full tensor, no full add
+        gs = [g for g in (gs[1:] if ctx.cls_first else gs) if g is not None]
         if not gs:
-            return None, None
+            return None, None, None
         total = gs[0]
         for g in gs[1:]:
             total = total + g
-        XF.keep(total, *gs)
-        return total, None
+        if narrow is not None:
+            if len(gs) == 1 and not total.is_contiguous():
+                total = total.contiguous()
+            total[:, :1] += narrow                          # in place: `total` is a fusion's freshly written dcat (this node is its only reader) or the sum above
+        XF.keep(total, *gs, narrow)
+        return total, None, None
 
 
 _SIDE_STREAMS: dict = {}
@@ -258,7 +268,9 @@ class MultiScaleBlock(nn.Module):
         alias = {}
         for i, a in enumerate(attn):
             fan = len(readers[i]) > 1 and a.is_cuda and a.requires_grad and os.environ.get("XVIT_FANOUT", "1") == "1"
-            outs_i = _FanOut.apply(a, len(readers[i])) if fan else [a] * len(readers[i])
+            # cls-only block: the own fusion reads nothing but the CLS rows of its modality: hand it those alone
+            cls_first = fan and cls_only and readers[i][0] == ("own", i) and self.attn_order.get(str(i)) != str(i) and os.environ.get("XVIT_CLS_NARROW", "1") == "1"
+            outs_i = _FanOut.apply(a, len(readers[i]), cls_first) if fan else [a] * len(readers[i])
             for r, t in zip(readers[i], outs_i):
                 alias[(i,) + r] = t
         thunks = []

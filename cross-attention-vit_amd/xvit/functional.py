@@ -475,7 +475,9 @@ def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq, bq, wkv_s, bkv, wp, bp, 
     d = xi.shape[1]
     scale = (d // H) ** -0.5
     hn, mu, rs = ops.layernorm_fwd(xj, ln1w, ln1b, eps, x_alt=xi, seq_len=N)
-    cls_in = xi.reshape(B, N * d)[:, :d]                   # un-normed CLS rows (row 0 of the concat; the residual, :112), ld = N*d
+    # un-normed CLS rows (row 0 of the concat; the residual, :112): rows 0, N, 2N, .. of the token tensor (ld = N*d), or xi itself when the
+    # caller hands just the packed [B, d] CLS rows
+    cls_in = xi if xi.shape[0] == B else xi.reshape(B, N * d)[:, :d]
     hn0f, _, _, _ = ops.layernorm_fwd_f32(cls_in, ln1w, ln1b, eps, want_bf16=False)
     qf, qb, _ = ops.linear_f32(hn0f, wq, bq, want_bf16=True)
     lowrank = wk is not None and _xattn_lowrank_ok(H, d, p)
@@ -588,10 +590,13 @@ class CrossFusionFn(Function):
 
     @staticmethod
     def forward(ctx, xi, xj, ln1w, ln1b, wq, bq, wk, bk, wv, bv, wp, bp, ln2w, ln2b, w1, b1, w2, b2, H, eps, concat, p=0.0, exclusive=False):
-        B, N, d = xi.shape
+        B, N, d = xj.shape
+        narrow = xi.shape[1] == 1 and N > 1                    # just the CLS rows of modality i (cls-only blocks, cross_vit._FanOut)
+        if narrow and concat:
+            raise ValueError("CrossFusionFn: a [B, 1, d] xi cannot be concatenated with patch tokens it does not carry")
         sh = (SHADOWS.get(wq), SHADOWS.get(wk, wv), SHADOWS.get(wp), SHADOWS.get(w1), SHADOWS.get(w2))
         bkv = torch.cat((bk, bv)).detach()
-        xi2, xj2 = _f32c(xi).reshape(B * N, d), _f32c(xj).reshape(B * N, d)
+        xi2, xj2 = _f32c(xi).reshape(B if narrow else B * N, d), _f32c(xj).reshape(B * N, d)
         seeds = drop_seeds(4) if p > 0.0 else (0, 0, 0, 0)
         # concat: the output is x_i with its CLS rows replaced by the fused token (model_cross.py:142) — by default a copy, as
         # the reference's torch.cat.  `exclusive` (set by MultiScaleBlock when ModelCross drives it, never by a direct caller):
@@ -605,7 +610,7 @@ class CrossFusionFn(Function):
         y2, saved = cross_forward(xi2, xj2, B, N, H, eps, ln1w, ln1b, wq.detach(), bq, sh[1], bkv, wp.detach(), bp, ln2w, ln2b, w1.detach(), b1,
                                   w2.detach(), b2, p, seeds, pack_cls=inplace, wk=wk.detach(), wv=wv.detach(), bv=bv.detach())
         ctx.drop = (p, seeds)
-        ctx.meta = (B, N, H, d, concat, inplace)
+        ctx.meta = (B, N, H, d, concat, inplace, narrow)
         ctx.save_for_backward(ln1w, ln2w, *sh, wk.detach(), wv.detach(), *saved)
         if not concat:
             return y2.reshape(B, 1, d)
@@ -618,7 +623,7 @@ class CrossFusionFn(Function):
 
     @staticmethod
     def backward(ctx, dout):
-        B, N, H, d, concat, inplace = ctx.meta
+        B, N, H, d, concat, inplace, narrow = ctx.meta
         ln1w, ln2w, wq_s, wkv_s, wp_s, w1_s, w2_s, wk_m, wv_m, *saved = ctx.saved_tensors
         dout = _f32c(dout)
         dy2 = dout[:, 0].contiguous()
@@ -629,6 +634,8 @@ class CrossFusionFn(Function):
             # exclusive form: the incoming gradient has this node as its only reader (see forward), so its CLS rows are replaced
             # where they are; otherwise the caller's grad_outputs / a gradient shared with another node stays untouched
             dxi = dout if inplace else dout.clone()
+        elif narrow:
+            dxi = torch.empty(B, 1, d, dtype=torch.float32, device=dout.device)       # xi was the CLS rows alone: so is its gradient
         else:
             dxi = torch.zeros(B, N, d, dtype=torch.float32, device=dout.device)
         dxi[:, 0] = dcat[:, 0] + dcls_res

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Patch embedding at configs[1] (B = 126, 2 modalities, 128^3 volumes, 16^3 patches, d = 768): the fused gather kernels
-against patchify + GEMM on a stored patch matrix, forward and weight gradient (HIP events)."""
+"""Patch embedding at configs[1] (B = 126, 2 modalities, 128^3 volumes, 16^3 patches, d = 768) — or, with `ucsf` as the second
+argument, at configs[2]'s shape (4 modalities, 240^3 volumes: 15 patches per axis, the per-K-step placement of the weight gradient):
+the fused gather kernels against patchify + GEMM on a stored patch matrix, forward and weight gradient (HIP events).
+    python tools/patch_embed_bench.py [B] [ucsf]"""
 import os
 import sys
 
@@ -12,9 +14,11 @@ from xvit import ops  # noqa: E402
 from xvit import functional as XF  # noqa: E402
 
 dev = torch.device("cuda:0")
-B, M, patch, d = int(sys.argv[1]) if len(sys.argv) > 1 else 126, 2, (16, 16, 16), 768
-img = torch.randn(B, M, 1, 128, 128, 128, device=dev).bfloat16()
-P, pd = 512, 4096
+UCSF = "ucsf" in sys.argv
+B, M, patch, d = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else (4 if UCSF else 126), 4 if UCSF else 2, (16, 16, 16), 768
+side = 240 if UCSF else 128
+img = torch.randn(B, M, 1, side, side, side, device=dev).bfloat16()
+P, pd = (side // 16) ** 3, 4096
 w = (torch.randn(d, pd, device=dev) / 64).bfloat16()
 bias, pos = torch.randn(d, device=dev), torch.randn(1 + P, d, device=dev)
 rows = M * B * (1 + P)

@@ -9,7 +9,7 @@ mkdir -p $S && S=$(cd $S && pwd)
 export TMPDIR=/tmp
 python3 bench.py > $S/bench_default.json 2> $S/bench_default.err || exit 1
 cd /tmp
-Q="--no-cpu-baseline --no-clock-probe --profile-steps 0 --no-small-batch"
+Q="--no-cpu-baseline --profile-steps 0 --no-small-batch"
 rocprofv3 --kernel-trace --stats --output-format csv -d $S/stats -- python3 $R/bench.py --steps 10 --warmup 3 $Q --single-stream > $S/stats.log 2>&1 || exit 2
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $S/fetch -- python3 $R/bench.py --steps 2 --warmup 1 $Q > $S/fetch.log 2>&1 || exit 3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $S/write -- python3 $R/bench.py --steps 2 --warmup 1 $Q > $S/write.log 2>&1 || exit 4
