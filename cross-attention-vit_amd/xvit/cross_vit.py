@@ -332,6 +332,8 @@ class ModelCross(EpochStatsMixin, _Base):
             self._sync_flat_weights()
         if img.shape[1] != self.num_modalities:
             raise ValueError(f"expected {self.num_modalities} modalities, got {img.shape[1]}")
+        if img.is_cuda and torch.is_grad_enabled():
+            XF.arena_begin(img.device)                   # the backward's small zeroed vectors: one fill per step (functional._zeros)
         tokens = XF.PatchEmbedFn.apply(img, self.patch_to_embedding.weight, self.patch_to_embedding.bias,
                                        self.cls_token, self.pos_embedding, self.patch_size, _p(self, self.dropout))
         x = list(tokens)

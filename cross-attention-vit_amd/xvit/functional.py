@@ -315,8 +315,28 @@ def _masked(t_b, p, seed):
     return ops.dropout(t_b, p, seed, out=t_b) if p > 0.0 else t_b
 
 
-def _zeros(n, ref):
-    return torch.zeros(n, dtype=torch.float32, device=ref.device)
+# One zero fill per step instead of ~28: the backward chains need many small zeroed fp32 vectors (the targets of atomically accumulated bias /
+# LayerNorm gradients, dpos, dcls, ...).  ModelCross.forward opens a fresh 4 MB arena (one fill, on the caller's stream, before any fork: it
+# happens-before every backward kernel); _zeros() hands out 256-byte aligned slices of it and falls back to torch.zeros when it is used up.
+# A slice is never handed out twice; gradients that ARE slices keep the arena's storage alive as long as they live.
+_ARENA = [None, 0]
+ARENA_FLOATS = 1 << 20
+
+
+def arena_begin(device):
+    _ARENA[0] = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=device)
+    _ARENA[1] = 0
+
+
+def _zeros(n, ref, shape=None):
+    a = _ARENA[0]
+    if a is not None and a.device == ref.device and _ARENA[1] + n <= a.numel():
+        o = _ARENA[1]
+        _ARENA[1] = o + (n + 63) // 64 * 64
+        out = a[o:o + n]
+    else:
+        out = torch.zeros(n, dtype=torch.float32, device=ref.device)
+    return out if shape is None else out.view(shape)
 
 
 def _f32c(t):
@@ -375,7 +395,7 @@ def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w
     LN2 backward (column sums of its dres and dx), b1 out of the GELU' dgrad epilogue."""
     x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a = saved
     d, f = x.shape[1], z.shape[1]
-    zero = torch.zeros(6 * d + f, dtype=torch.float32, device=x.device)   # every atomically-accumulated vector of this block
+    zero = _zeros(6 * d + f, x)                               # every atomically-accumulated vector of this block
     g = dict(zip(("ln2w", "ln2b", "bo", "b2", "ln1w", "ln1b"), zero[:6 * d].split(d)))
     g["b1"] = zero[6 * d:]
     dyb = _masked(ops.cast_bf16(dy), p_ffn, seeds[2])        # d(FFN out) = dy * mask
@@ -518,7 +538,7 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
         xi, xj, mu, rs, hn, kv, q, oc, p, y, mu2, rs2, h2, z, a = saved       # xi: the token tensor or a packed copy of its CLS rows
     d, f = xi.shape[1], z.shape[1]
     scale = (d // H) ** -0.5
-    zero = torch.zeros(7 * d + f, dtype=torch.float32, device=xi.device)
+    zero = _zeros(7 * d + f, xi)
     g = dict(zip(("ln2w", "ln2b", "bp", "b2", "ln1w", "ln1b", "bk0"), zero[:7 * d].split(d)))
     g["b1"] = zero[7 * d:]
     bk0 = g.pop("bk0")                                                    # stays zero: wk.bias has no gradient (softmax shift invariance)
@@ -695,8 +715,8 @@ class PatchEmbedFn(Function):
         M, Bn, N, d, p, seed, fused_patch = ctx.meta
         patches, w_s = ctx.saved_tensors
         dev = patches.device
-        dpos = torch.zeros(N, d, dtype=torch.float32, device=dev)
-        dcls = torch.zeros(d, dtype=torch.float32, device=dev)
+        dpos = _zeros(N * d, patches, (N, d))
+        dcls = _zeros(d, patches)
         if len(dxs) == 1 or p > 0.0:         # single sequence (ModelVIT), or dropout (its mask is keyed by the index in the stacked tensor)
             dx = dxs[0] if len(dxs) == 1 else torch.stack([_f32c(g) for g in dxs])
             dx2 = _f32c(dx).reshape(M * Bn * N, d)
@@ -752,7 +772,7 @@ class HeadFn(Function):
         dl = _f32c(dl)
         if p > 0.0:
             dl = ops.dropout(dl, p, seeds[1])
-        dW3, db3 = torch.zeros_like(w3), _zeros(w3.shape[0], dl)
+        dW3, db3 = _zeros(w3.numel(), dl, tuple(w3.shape)), _zeros(w3.shape[0], dl)
         dz = _masked(ops.small_linear_bwd(dl, a, w3.detach(), dW3, db3, z=z), p, seeds[0])
         dh = _dgrad(dz, w0_s)
         dW0 = _wgrad(dz, h, w0_s)
@@ -760,7 +780,7 @@ class HeadFn(Function):
         dg, dbeta = _zeros(d, dl), _zeros(d, dl)
         dxc, _ = ops.layernorm_bwd(dh, x2, mu, rs, lnw, dg, dbeta)
         _join_wgrads(dl.device)
-        dx = torch.zeros(B, N, d, dtype=torch.float32, device=dl.device)
+        dx = _zeros(B * d, dl, (B, 1, d)) if N == 1 else torch.zeros(B, N, d, dtype=torch.float32, device=dl.device)
         dx[:, 0] = dxc
         keep(dx)
         return dx, dg, dbeta, dW0, db0, dW3, db3, None, None
