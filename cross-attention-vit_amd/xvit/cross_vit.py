@@ -182,6 +182,11 @@ class _FanOut(torch.autograd.Function):
 
 
 _SIDE_STREAMS: dict = {}
+# per-context override of XVIT_STREAMS (xvit.graph.GraphedStep captures with its own mode without touching the process environment,
+# which another thread running a model would see)
+import contextvars  # noqa: E402
+
+STREAM_MODE: "contextvars.ContextVar[str | None]" = contextvars.ContextVar("xvit_stream_mode", default=None)
 
 
 def _side_streams(device, n, kind="branches"):
@@ -214,7 +219,7 @@ class MultiScaleBlock(nn.Module):
         tiny CLS-row launches of the two fusions overlap each other).  `thunks[i]` is None for a pass-through (nothing
         to launch: no fork).  `tensors` are the inputs the side streams read.  autograd replays backward on the same
         streams."""
-        mode = os.environ.get("XVIT_STREAMS", "1")     # "1": branches and fusions, "branches": branches only, "0": one stream
+        mode = STREAM_MODE.get() or os.environ.get("XVIT_STREAMS", "1")     # "1": branches and fusions, "branches": branches only, "0": one stream
         work = [i for i, f in enumerate(thunks) if f is not None]
         outs = [None] * len(thunks)
         if len(work) < 2 or not tensors[0].is_cuda or mode == "0" or (mode == "branches" and kind != "branches"):

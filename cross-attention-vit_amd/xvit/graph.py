@@ -61,10 +61,11 @@ class GraphedStep:
                     b.flat.zero_()
         self.img = img.clone()
         self.labels = labels.clone()
-        self._prev_streams = os.environ.get("XVIT_STREAMS")
         # XVIT_GRAPH_STREAMS: "1" (default) forks the branches AND the fusions inside the capture (parallel graph paths),
-        # "branches" only the self-attention branches, "0" captures everything on one stream.
-        os.environ["XVIT_STREAMS"] = {"0": "0", "branches": "branches"}.get(os.environ.get("XVIT_GRAPH_STREAMS", "1"), "1")
+        # "branches" only the self-attention branches, "0" captures everything on one stream.  Set as a context variable
+        # (cross_vit.STREAM_MODE), not through os.environ: another thread's model keeps its own mode.
+        from .cross_vit import STREAM_MODE
+        self._mode_token = STREAM_MODE.set({"0": "0", "branches": "branches"}.get(os.environ.get("XVIT_GRAPH_STREAMS", "1"), "1"))
         try:
             side = torch.cuda.Stream(device=img.device)
             side.wait_stream(torch.cuda.current_stream(img.device))
@@ -91,10 +92,10 @@ class GraphedStep:
             self._restore_env()                    # also when warm-up or capture raises: never leave the process in capture mode
 
     def _restore_env(self):
-        if self._prev_streams is None:
-            os.environ.pop("XVIT_STREAMS", None)
-        else:
-            os.environ["XVIT_STREAMS"] = self._prev_streams
+        from .cross_vit import STREAM_MODE
+        if self._mode_token is not None:
+            STREAM_MODE.reset(self._mode_token)
+            self._mode_token = None
 
     def _eager(self, zero=True):
         if zero:

@@ -32,6 +32,33 @@ def test_argument_errors_do_not_launch():
     assert lib.xvit_set_option(b"no_such_option", 1) < 0 and lib.xvit_set_option(b"gemm_tile", 0) == 0
 
 
+def test_attention_workspaces_and_peel_predicate():
+    """Host-only: which shapes take the CLS-peel form (N = 64 m + 1, no probability dropout, large grids unless forced), the sizes of the
+    caller-owned workspaces, and that too small a workspace is refused before any launch."""
+    from xvit import _lib
+    lib = _lib.load()
+    fw, bw = lib.xvit_attn_fwd_workspace_bytes, lib.xvit_attn_bwd_workspace_bytes
+    assert fw(126, 12, 513) == 126 * 12 * 16 * 80 * 4                 # one 80-float slot per wave: (N - 1) / 32 = 16 slots per (b, head)
+    assert fw(126, 12, 512) == 0 and fw(126, 12, 3376) == 0 and fw(8, 12, 513) == 0    # not 64 m + 1 / a grid of 384 workgroups
+    assert fw(8, 12, 4097) > 0                                         # configs[4]: 3072 workgroups
+    assert bw(126, 12, 513) == (2 * 126 * 12 * 513 + 3 * 126 * 12 * 16 * 64) * 4
+    assert bw(8, 12, 513) == 2 * 8 * 12 * 513 * 4
+    try:
+        assert lib.xvit_set_option(b"attn_peel", 2) == 0
+        assert fw(8, 12, 513) > 0 and fw(2, 3, 65) > 0 and fw(2, 3, 1) == 0
+        assert lib.xvit_set_option(b"attn_peel", 0) == 0
+        assert fw(126, 12, 513) == 0
+        assert lib.xvit_set_option(b"attn_peel", 3) < 0
+    finally:
+        lib.xvit_set_option(b"attn_peel", 1)
+    # a workspace that is too small is an argument error (nothing is launched: callable without a GPU; the pointers are never dereferenced)
+    d = 12 * 64
+    rc = lib.xvit_attn_fwd(64, 64, 64, 513 * 3 * d, 3 * d, 64, 513 * d, d, 64, 126, 12, 513, 64, 0.125, 0.0, 0, 64, 1024, None)
+    assert rc < 0 and b"workspace" in lib.xvit_last_error_string()
+    rc = lib.xvit_attn_bwd(64, 64, 64, 513 * 3 * d, 3 * d, 64, 64, 513 * d, d, 64, 64, 1024, 64, 64, 64, 126, 12, 513, 64, 0.125, 0.0, 0, None)
+    assert rc < 0 and b"workspace" in lib.xvit_last_error_string()
+
+
 def test_modules_have_reference_state_dict_keys():
     import ref_cpu as R
     import xvit
