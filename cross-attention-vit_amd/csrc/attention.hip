@@ -1039,16 +1039,18 @@ static int attn_check(const char* who, int B, int H, int N, int dh, int64_t sb, 
 static DropArgs drop_args(float p, uint64_t seed) { return DropArgs{(uint32_t)(p * 16777216.0f), 1.0f / (1.0f - p), seed}; }
 
 // xvit_set_option("attn_peel"): 0 = never; 2 = token 0 off the tile grid whenever N = 64 m + 1 and no probability dropout; 1 (default) = that,
-// on grids of >= 2560 workgroups only.  On a grid the chip holds in one or two rounds a launch takes as long as its slowest
-// workgroup, and the peeled workgroup (8 tiles + token-0 prologue and post-loop block, then the merge launch) is not shorter than
-// the grid form's (9 tiles): B = 8, N = 513: 21.0 vs 17.5 us forward, 53 vs 44 us backward; B = 32: equal; B = 126: 165 vs 182, 514 vs 536;
-// B = 8, N = 4097 (3072 workgroups): 491 vs 523, 1423 vs 1460 (tools/attn_peel_bench.py, one box, interleaved).
+// on grids of >= 768 workgroups only.  On a grid the chip holds in a single round a launch takes as long as its slowest workgroup,
+// and the peeled workgroup (8 tiles + token-0 prologue and post-loop block, then the merge launch) is not shorter than the grid
+// form's (9 tiles).  tools/attn_peel_bench.py, one box, interleaved, forward / backward us, peel vs grid:
+//   N = 513:  B = 8 (384 workgroups) 21.4 vs 17.5 / 53 vs 45;  B = 16 (768) 29.6 vs 31.0 / 78 vs 81;  B = 24 39.4 vs 39.8 / 112 vs 108;
+//             B = 32 46 vs 52 / 134 vs 143;  B = 48 64 vs 72 / 193 vs 203;  B = 126 167 vs 180 / 508 vs 535
+//   N = 4097: B = 4 (1536 workgroups) 252 vs 284 / 716 vs 764;  B = 8 474 vs 511 / 1384 vs 1422
 static std::atomic<int> g_attn_peel{1};
 namespace xvit { void set_attn_peel(int v) { g_attn_peel.store(v, std::memory_order_relaxed); } }
 static bool peel_shape(int B, int H, int N, float dropout_p) {
   const int mode = g_attn_peel.load(std::memory_order_relaxed);
   if (mode == 0 || N <= 1 || (N - 1) % 64 != 0 || dropout_p != 0.f) return false;
-  return mode == 2 || (int64_t)B * H * ((N - 1 + 127) / 128) >= 2560;
+  return mode == 2 || (int64_t)B * H * ((N - 1 + 127) / 128) >= 768;
 }
 
 extern "C" int64_t xvit_attn_fwd_workspace_bytes(int B, int H, int N) {

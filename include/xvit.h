@@ -158,7 +158,7 @@ int xvit_attn_bwd(const void* q, const void* k, const void* v, int64_t stride_b,
 /* CLS peel.  The reference's sequences are cls + P patch tokens (model_cross.py:195-196): N = 64 m + 1 at every BASELINE config with
  * cubic power-of-two volumes (513, 1025, 4097).  On a tile grid token 0 costs one more 128-query block per (b, head) and one more
  * 64-key tile per block.  With a workspace (xvit_attn_fwd_workspace_bytes > 0 <=> the shape qualifies: N % 64 == 1, no probability
- * dropout, and under the default xvit_set_option("attn_peel", 1) a grid of >= 2560 workgroups; 2 = any grid, 0 = never) the kernels tile the patch tokens only; token 0 enters as the initial
+ * dropout, and under the default xvit_set_option("attn_peel", 1) a grid of >= 768 workgroups; 2 = any grid, 0 = never) the kernels tile the patch tokens only; token 0 enters as the initial
  * online-softmax state / initial gradient accumulators (as a key) and as one extra MFMA block per wave with partial results merged
  * in a fixed order (as a query).  Same outputs (o, lse, dq, dk, dv for all N tokens), bit-reproducible; workspace == NULL keeps
  * token 0 on the tile grid. */

@@ -39,8 +39,8 @@ def test_attention_workspaces_and_peel_predicate():
     lib = _lib.load()
     fw, bw = lib.xvit_attn_fwd_workspace_bytes, lib.xvit_attn_bwd_workspace_bytes
     assert fw(126, 12, 513) == 126 * 12 * 16 * 80 * 4                 # one 80-float slot per wave: (N - 1) / 32 = 16 slots per (b, head)
-    assert fw(126, 12, 512) == 0 and fw(126, 12, 3376) == 0 and fw(8, 12, 513) == 0    # not 64 m + 1 / a grid of 384 workgroups
-    assert fw(8, 12, 4097) > 0                                         # configs[4]: 3072 workgroups
+    assert fw(126, 12, 512) == 0 and fw(126, 12, 3376) == 0 and fw(8, 12, 513) == 0    # not 64 m + 1 / a grid of 384 workgroups (< 768)
+    assert fw(8, 12, 4097) > 0 and fw(16, 12, 513) > 0                 # configs[4]: 3072 workgroups; 768 workgroups
     assert bw(126, 12, 513) == (2 * 126 * 12 * 513 + 3 * 126 * 12 * 16 * 64) * 4
     assert bw(8, 12, 513) == 2 * 8 * 12 * 513 * 4
     try:
