@@ -37,7 +37,7 @@ def build(force: bool = False, verbose: bool = True, out: str = OUT, defines=())
 
     def compile_one(src):
         obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *[f"-D{d}" for d in defines], "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *os.environ.get("XVIT_EXTRA_FLAGS", "").split(), *[f"-D{d}" for d in defines], "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
