@@ -85,6 +85,7 @@ class GraphedStep:
             if reducer is not None:
                 for p in self.params:              # from now on p.grad IS the bucket view the graph's collectives reduce in place
                     p.grad = reducer._view_of[id(p)]
+            self._grads = [p.grad for p in self.params]   # static buffers of the graph: handed back at every call (zero_grad(set_to_none=True) drops them)
             # the graph holds raw addresses: remember where the parameters (and the flat weight buffers) live
             self._ptrs = [p.data_ptr() for p in self.params]
             self._flat = getattr(model, "_flat", None)
@@ -132,4 +133,6 @@ class GraphedStep:
         if labels is not None:
             self.labels.copy_(labels, non_blocking=True)
         self.graph.replay()
+        for p, g in zip(self.params, self._grads):
+            p.grad = g
         return self.logits, self.loss

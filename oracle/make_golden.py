@@ -308,21 +308,27 @@ def golden_model_vit(ns, ConfigDict, chk: Checker):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true", help="verify only; do not write fixtures")
-    ap.add_argument("--skip-base", action="store_true", help="skip the 93M-parameter config[1] case")
+    ap.add_argument("--skip-base", action="store_true", help="skip the 93M-parameter config[1] case and the 242M-parameter reference-default case")
+    ap.add_argument("--only", action="append", default=[], help="make only this fixture file (repeatable), e.g. --only model_cross_mist.npz")
     args = ap.parse_args()
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
     Mref, ns, ConfigDict = import_reference()
     chk = Checker()
-    files = {
-        "blocks.npz": golden_blocks(Mref, ConfigDict, chk),
-        "encoder.npz": golden_encoder(ns, ConfigDict, chk),
-        "model_vit_small.npz": golden_model_vit(ns, ConfigDict, chk),
-        "model_cross_tiny.npz": golden_model_cross(Mref, ConfigDict, "tiny", 4, chk, full=True),
-        "model_cross_small.npz": golden_model_cross(Mref, ConfigDict, "small", 2, chk, full=True),
+    makers = {
+        "blocks.npz": lambda: golden_blocks(Mref, ConfigDict, chk),
+        "encoder.npz": lambda: golden_encoder(ns, ConfigDict, chk),
+        "model_vit_small.npz": lambda: golden_model_vit(ns, ConfigDict, chk),
+        "model_cross_tiny.npz": lambda: golden_model_cross(Mref, ConfigDict, "tiny", 4, chk, full=True),
+        "model_cross_small.npz": lambda: golden_model_cross(Mref, ConfigDict, "small", 2, chk, full=True),
     }
     if not args.skip_base:
-        files["model_cross_base.npz"] = golden_model_cross(Mref, ConfigDict, "base", 2, chk, full=False)
+        makers["model_cross_base.npz"] = lambda: golden_model_cross(Mref, ConfigDict, "base", 2, chk, full=False)
+        # the reference's own run shape (config2.py:5-22, main_mist.py:71): d = 1024, 16 heads, 3-ring, 16 x 16 x 8 patches
+        makers["model_cross_mist.npz"] = lambda: golden_model_cross(Mref, ConfigDict, "mist", 2, chk, full=False)
+    unknown = [fn for fn in args.only if fn not in makers]
+    assert not unknown, f"unknown fixture(s) {unknown}; have {sorted(makers)}"
+    files = {fn: make() for fn, make in makers.items() if not args.only or fn in args.only}
     print(f"restatement == reference on {len(chk.rows)} tensors; worst rel-L2 {chk.worst:.3e}")
     if not args.check:
         os.makedirs(GOLD, exist_ok=True)

@@ -60,6 +60,10 @@ def make_config(name: str = "tiny", **over) -> SimpleNamespace:
         "ucsf": dict(hidden_dim=768, mlp_dim=3072, num_heads=12, num_multi_blocks=2,
                      num_self_blocks=2, img_size=(240, 240, 240), patch_size=(16, 16, 16),
                      num_modalities=4, attn_order={"0": "1", "1": "2", "2": "3", "3": "0"}),
+        # the reference's own run shape (config2.py:5-22 + main_mist.py:71): 3-ring, thin W patches (8-voxel runs), d_h = 64 at 16 heads
+        "mist": dict(hidden_dim=1024, mlp_dim=4096, num_heads=16, num_multi_blocks=2,
+                     num_self_blocks=2, img_size=(128, 128, 64), patch_size=(16, 16, 8),
+                     num_modalities=3, attn_order={"0": "1", "1": "2", "2": "0"}),
         # config[4]: long sequence
         "long": dict(hidden_dim=768, mlp_dim=3072, num_heads=12, num_multi_blocks=2,
                      num_self_blocks=2, img_size=(128, 128, 128), patch_size=(8, 8, 8)),

@@ -43,6 +43,13 @@ def test_graphed_step_matches_eager_and_follows_new_inputs():
     assert float(loss) != e1[1]
     ref = eager(img1, lab1)
     assert rel(logits, ref[0]) < 1e-6 and abs(float(loss) - ref[1]) < 1e-6
+    # the reference's loop drops the gradients between steps (zero_grad(set_to_none=True)): a replay hands the static buffers back
+    opt.zero_grad(set_to_none=True)
+    assert all(p.grad is None for p in model.parameters())
+    step(img1, lab1)
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        assert p.grad is not None and (rel(p.grad, ref[2][k]) < 1e-5 or float(ref[2][k].abs().max()) < 1e-6), k
 
 
 def test_graphed_step_survives_a_stale_autograd_graph():

@@ -136,7 +136,7 @@ def _run_model(name, batch):
     return cfg, sd, img, labels, model, caps, logits, loss
 
 
-@pytest.mark.parametrize("name,batch", [("tiny", 4), ("small", 2), ("base", 2)])
+@pytest.mark.parametrize("name,batch", [("tiny", 4), ("small", 2), ("base", 2), ("mist", 2)])   # mist: the reference's own run shape (main_mist.py:71)
 def test_model_cross_vs_reference_golden(golden_dir, name, batch):
     _check_model_vs_golden(golden_dir, name, batch)
 
@@ -158,7 +158,11 @@ def _check_model_vs_golden(golden_dir, name, batch):
     assert str(g["img_sha256"]) == R.tensor_sha256(img)  # same inputs the reference saw
     # logits: 2-class sums with heavy cancellation (|logit| ~ 0.01 .. 0.3 from a head whose terms are O(1)); measured 1.4e-2 at
     # configs[1], of which the bf16-emulating oracle shows 1.2e-2 itself (the CLS rows it feeds on differ by 5e-3 from fp32)
-    assert rel(logits, _t(g["logits"])) < 1.8e-2, rel(logits, _t(g["logits"]))
+    # At the reference's own run shape (mist: three heads of width 4096 on 1024-wide CLS rows, |logit| 0.02 .. 0.15) the same 5.7e-3 on the
+    # CLS rows becomes 2.9e-2 on the four logits; the bf16-emulating oracle sits at 3.0e-2 from this fixture itself and 1.6e-2 from the GPU
+    # (tests/_probe_golden_distances.py mist 2 -> profiles/r03_parity_probe.txt).  Every other gate below is the one of configs[1].
+    logit_tol = 4.5e-2 if name == "mist" else 1.8e-2
+    assert rel(logits, _t(g["logits"])) < logit_tol, rel(logits, _t(g["logits"]))
     assert abs(float(loss.detach()) - float(g["loss"])) < 5e-3
     for b in range(cfg.num_multi_blocks):
         for m in range(cfg.num_modalities):
@@ -321,10 +325,11 @@ def test_accumulates_like_autograd_and_fails_loudly_off_gpu():
     model(img.to(dev()), labels.to(dev()))
 
 
-@pytest.mark.parametrize("name,batch", [("long", 1), ("ucsf", 1)])
+@pytest.mark.parametrize("name,batch", [("long", 1), ("ucsf", 1), ("mist", 2)])
 def test_large_configs_vs_bf16_emulating_oracle(name, batch):
-    """BASELINE.json configs[4] (128^3, 8^3 patches -> N = 4097) and configs[2] (4 modalities, 240^3 ->
-    N = 3376, 4-ring): forward parity against the emulating oracle at batch 1, EVERY parameter gradient's norm against the
+    """BASELINE.json configs[4] (128^3, 8^3 patches -> N = 4097), configs[2] (4 modalities, 240^3 ->
+    N = 3376, 4-ring) and the reference's own run shape (config2.py + main_mist.py:71: d = 1024, 16 heads, mlp 4096, three modalities of
+    128 x 128 x 64 in a ring, 16 x 16 x 8 patches -> N = 513; 242 M parameters): forward parity against the emulating oracle at batch 1, EVERY parameter gradient's norm against the
     oracle's autograd (1 %), and a size-independent property of the path — each CLS-fused stream keeps its own patch tokens untouched by
     the fusion step (model_cross.py:142), checked through the backward: d loss / d img is non-zero for
     every modality."""
@@ -360,7 +365,7 @@ def test_large_configs_vs_bf16_emulating_oracle(name, batch):
             continue
         ref_n, got_n = float(leaf[k].grad.double().norm()), float(p.grad.double().norm())
         worst = max(worst, abs(got_n - ref_n) / (ref_n + 1e-12))
-        assert abs(got_n - ref_n) <= 0.01 * ref_n + 1e-7, (k, got_n, ref_n)      # measured worst: 1.2e-3 (long), 2.8e-3 (ucsf)
+        assert abs(got_n - ref_n) <= 0.01 * ref_n + 1e-7, (k, got_n, ref_n)      # measured worst: 1.2e-3 (long), 2.8e-3 (ucsf); mist passes the same 1 % (3.5e-3 against the fp32 fixture)
     note(f"large_config.{name}.worst_grad_norm_dev", worst)
 
 

@@ -108,6 +108,27 @@ def test_base_logits_golden_present(golden_dir):
     assert g["logits"].shape == (2, 2) and np.isfinite(g["logits"]).all()
 
 
+def test_reference_run_shape_matches_reference(golden_dir):
+    """The reference's own run shape (config2.py:5-22 + main_mist.py:71: d = 1024, 16 heads, mlp 4096, three 128 x 128 x 64 modalities in a
+    ring, 16 x 16 x 8 patches; 241.95 M parameters, SURVEY.md section 8 shape ladder): the restatement's forward against the fixture
+    oracle/make_golden.py wrote from the imported reference."""
+    cfg = R.make_config("mist")
+    fwd, both = R.flops_per_sample(cfg)
+    assert abs(fwd / 1e9 - 187.4) < 0.1 and abs(both / 1e9 - 555.7) < 0.1
+    g = np.load(os.path.join(golden_dir, "model_cross_mist.npz"))
+    sd = R.make_state_dict(cfg, seed=0)
+    assert sum(v.numel() for v in sd.values()) == 241_945_606
+    img, labels = R.make_inputs(cfg, int(g["batch"]), seed=0)
+    assert str(g["img_sha256"]) == R.tensor_sha256(img)
+    cap = {}
+    with torch.no_grad():
+        logits, loss = R.model_cross_forward(sd, img, labels, cfg, capture=cap)
+    assert rel(logits, torch.from_numpy(g["logits"])) < 2e-5 and abs(float(loss) - float(g["loss"])) < 2e-6
+    for b in range(cfg.num_multi_blocks):
+        for m in range(cfg.num_modalities):
+            assert rel(cap[f"msb{b}"][m][:, 0], torch.from_numpy(g[f"msb{b}/mod{m}/cls"])) < 2e-5
+
+
 def test_model_vit_matches_reference(golden_dir):
     """modelv3.ModelVIT (the reference's concatenated-token comparison arm)."""
     g = np.load(os.path.join(golden_dir, "model_vit_small.npz"))
