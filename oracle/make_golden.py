@@ -142,8 +142,8 @@ class Checker:
 
 
 # ------------------------------------------------------------------ ModelCross goldens
-def golden_model_cross(Mref, ConfigDict, name, batch, chk: Checker, full: bool):
-    cfg = R.make_config(name)
+def golden_model_cross(Mref, ConfigDict, name, batch, chk: Checker, full: bool, **over):
+    cfg = R.make_config(name, **over)
     sd = R.make_state_dict(cfg, seed=0)
     img, labels = R.make_inputs(cfg, batch, seed=0)
     model = Mref.ModelCross(to_ref_config(cfg, ConfigDict))
@@ -305,6 +305,9 @@ def golden_model_vit(ns, ConfigDict, chk: Checker):
     return out
 
 
+PARTIAL = dict(num_modalities=3, attn_order={"0": "1", "1": "2"})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true", help="verify only; do not write fixtures")
@@ -322,6 +325,8 @@ def main():
         "model_cross_tiny.npz": lambda: golden_model_cross(Mref, ConfigDict, "tiny", 4, chk, full=True),
         "model_cross_small.npz": lambda: golden_model_cross(Mref, ConfigDict, "small", 2, chk, full=True),
     }
+    # the reference's second run setting (main_mist.py:72): three modalities, only two of them fused (0 <- 1, 1 <- 2; modality 2 passes through)
+    makers["model_cross_partial.npz"] = lambda: golden_model_cross(Mref, ConfigDict, "tiny", 3, chk, full=True, **PARTIAL)
     if not args.skip_base:
         makers["model_cross_base.npz"] = lambda: golden_model_cross(Mref, ConfigDict, "base", 2, chk, full=False)
         # the reference's own run shape (config2.py:5-22, main_mist.py:71): d = 1024, 16 heads, 3-ring, 16 x 16 x 8 patches
