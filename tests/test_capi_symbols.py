@@ -59,6 +59,24 @@ def test_attention_workspaces_and_peel_predicate():
     assert rc < 0 and b"workspace" in lib.xvit_last_error_string()
 
 
+def test_head_linear_argument_errors_do_not_launch():
+    """The low-rank fusion's per-head kernels (csrc/head_linear.hip) refuse bad shapes on the host: d != 64 H, more than 16 heads in the
+    CLS softmax, misaligned strides, null pointers.  Pointers are never dereferenced (no launch): callable without a GPU."""
+    from xvit import _lib
+    lib = _lib.load()
+    P = 256   # any non-null, 16-byte aligned "address"
+    assert lib.xvit_head_rows(None, 768, P, 768, P, 768, 64, None, 0, 0, 0, 8, 12, 768, None) < 0 and b"null" in lib.xvit_last_error_string()
+    assert lib.xvit_head_rows(P, 768, P, 768, P, 768, 64, None, 0, 0, 0, 8, 12, 700, None) < 0 and b"64 H" in lib.xvit_last_error_string()
+    assert lib.xvit_head_rows(P, 766, P, 768, P, 768, 64, None, 0, 0, 0, 8, 12, 768, None) < 0            # ldx not a multiple of 4 floats / < d
+    assert lib.xvit_head_cols(P, 768, 64, P, 766, None, 0, None, P, 768, None, 0, 8, 12, 768, None) < 0   # ldw not a multiple of 4 floats
+    assert lib.xvit_head_cols(P + 4, 768, 64, P, 768, None, 0, None, P, 768, None, 0, 8, 12, 768, None) < 0   # t not 16-byte aligned
+    assert lib.xvit_head_wgrad(P, 512, P, 768, 64, None, 0, P, 768, 8, 12, 768, None) < 0                 # ldx < d
+    assert lib.xvit_cls_softmax_fwd(P, 32, P, 16, P, 8, 32, 513, 0.125, None) < 0 and b"H <= 16" in lib.xvit_last_error_string()
+    assert lib.xvit_cls_softmax_fwd(P, 12, P, 8, P, 8, 12, 513, 0.125, None) < 0                          # lde < H
+    assert lib.xvit_cls_softmax_bwd(P, 16, P, P, 12, P, P, 32, 8, 12, 513, 0.125, None) < 0               # ldb > 16
+    assert lib.xvit_cls_softmax_bwd(P, 16, None, P, 12, P, P, 16, 8, 12, 513, 0.125, None) < 0            # null rz
+
+
 def test_modules_have_reference_state_dict_keys():
     import ref_cpu as R
     import xvit
