@@ -275,7 +275,8 @@ __device__ __forceinline__ void store_col0(const f32x16 (&acc)[2], float* dst, i
 // kept iff hash32(seed, ((b H + h) N + query) N + key) >= p 2^24 — the mask xvit_dropout applies to a contiguous [B, H, N, N]
 // tensor with the same seed — and scaled by 1/(1-p).  The row sums (softmax normaliser) use the probabilities BEFORE the
 // mask; the backward kernels regenerate the mask (nothing is stored) and, with O = P_drop V, delta = rowsum(dO O) is unchanged.
-struct DropArgs { uint32_t thr; float inv; uint64_t seed; };
+struct DropArgs { uint32_t thr; float inv; uint64_t seed; const uint64_t* epoch; };   // epoch: xvit_common.h drop_seed_at (captured steps), or nullptr
+__device__ __forceinline__ DropArgs drop_at_run_time(DropArgs d) { d.seed = drop_seed_at(d.seed, d.epoch); return d; }
 __device__ __forceinline__ bool drop_keep(const DropArgs& d, uint64_t bh_base, int query, int key, int N) {
   return (hash32(d.seed, bh_base + (uint64_t)query * (uint64_t)N + (uint64_t)key) & 0xFFFFFFu) >= d.thr;
 }
@@ -298,7 +299,8 @@ constexpr int FWD_KS = 4, FWD_SS = 2;
 template <int QB, bool DROP, bool PEEL>
 __global__ __launch_bounds__(256, QB == 1 ? 4 : 2) void attn_fwd_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                           int64_t sb, int64_t sn, bf16* __restrict__ o, int64_t osb, int64_t osn,
-                                                          float* __restrict__ lse, int H, int N, float scale, const DropArgs drop, float* __restrict__ cls_ws) {
+                                                          float* __restrict__ lse, int H, int N, float scale, const DropArgs drop_in, float* __restrict__ cls_ws) {
+  const DropArgs drop = DROP ? drop_at_run_time(drop_in) : drop_in;   // captured steps: seed + device-side epoch
   static_assert(!PEEL || (QB == 1 && !DROP), "the CLS peel is built for 32 queries per wave, no probability dropout");
 #ifdef XVIT_DEBUG_ATTN_TIMES
   const uint64_t wc_entry = wall_clock64();
@@ -584,8 +586,9 @@ template <bool DROP, bool PEEL>
 __global__ __launch_bounds__(256, PEEL ? XVIT_DQ_PEEL_WAVES : 2) void attn_bwd_dq_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                              int64_t sb, int64_t sn, const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb,
                                                              int64_t osn, const float* __restrict__ lse, float* __restrict__ nlse_ws,
-                                                             float* __restrict__ delta, bf16* __restrict__ dq, int H, int N, float scale, const DropArgs drop,
+                                                             float* __restrict__ delta, bf16* __restrict__ dq, int H, int N, float scale, const DropArgs drop_in,
                                                              float* __restrict__ pdq) {
+  const DropArgs drop = DROP ? drop_at_run_time(drop_in) : drop_in;   // captured steps: seed + device-side epoch
   static_assert(!PEEL || !DROP, "the CLS peel is built without probability dropout");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
@@ -775,8 +778,9 @@ template <bool DROP, bool PEEL>
 __global__ __launch_bounds__(256, PEEL ? XVIT_DKV_PEEL_WAVES : 2) void attn_bwd_dkv_kernel(const bf16* __restrict__ q, const bf16* __restrict__ k, const bf16* __restrict__ v,
                                                               int64_t sb, int64_t sn, const bf16* __restrict__ o, const bf16* __restrict__ d_o, int64_t osb, int64_t osn,
                                                               const float* __restrict__ lse, const float* __restrict__ nlse_ws, const float* __restrict__ delta,
-                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int H, int N, float scale, const DropArgs drop,
+                                                              bf16* __restrict__ dk, bf16* __restrict__ dv, int H, int N, float scale, const DropArgs drop_in,
                                                               float* __restrict__ pdk, float* __restrict__ pdv) {
+  const DropArgs drop = DROP ? drop_at_run_time(drop_in) : drop_in;   // captured steps: seed + device-side epoch
   static_assert(!PEEL || !DROP, "the CLS peel is built without probability dropout");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   XVIT_LDS char* smem = (XVIT_LDS char*)smem_raw;
@@ -1036,7 +1040,7 @@ static int attn_check(const char* who, int B, int H, int N, int dh, int64_t sb, 
   return XVIT_OK;
 }
 
-static DropArgs drop_args(float p, uint64_t seed) { return DropArgs{(uint32_t)(p * 16777216.0f), 1.0f / (1.0f - p), seed}; }
+static DropArgs drop_args(float p, uint64_t seed) { return DropArgs{(uint32_t)(p * 16777216.0f), 1.0f / (1.0f - p), seed, p > 0.f ? drop_epoch_ptr() : nullptr}; }
 
 // xvit_set_option("attn_peel"): 0 = never; 2 = token 0 off the tile grid whenever N = 64 m + 1 and no probability dropout; 1 (default) = that,
 // on grids of >= 768 workgroups only.  On a grid the chip holds in a single round a launch takes as long as its slowest workgroup,

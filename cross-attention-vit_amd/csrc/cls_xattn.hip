@@ -38,7 +38,8 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_fwd_kernel(const bf16* _
                                                                    const bf16* __restrict__ k, const bf16* __restrict__ v, int64_t sb, int64_t sn,
                                                                    bf16* __restrict__ o, int64_t ldo, float* __restrict__ o_f32, int64_t ldof,
                                                                    float* __restrict__ p, int H, int N, float scale, float drop_p,
-                                                                   uint64_t drop_seed) {
+                                                                   uint64_t drop_seed_in, const uint64_t* __restrict__ drop_epoch) {
+  const uint64_t drop_seed = drop_seed_at(drop_seed_in, drop_epoch);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* sc = (float*)smem_raw;            // [N] scores -> probabilities
   float* red = sc + ((N + 3) & ~3);        // [4] + [32][64] partial outputs
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_bwd_kernel(const bf16* _
                                                                    const float* __restrict__ p, const bf16* __restrict__ d_o, int64_t lddo,
                                                                    float* __restrict__ dq, int64_t lddq, bf16* __restrict__ dk,
                                                                    bf16* __restrict__ dv, float* __restrict__ coef, int H, int N, float scale,
-                                                                   float drop_p, uint64_t drop_seed) {
+                                                                   float drop_p, uint64_t drop_seed_in, const uint64_t* __restrict__ drop_epoch) {
+  const uint64_t drop_seed = drop_seed_at(drop_seed_in, drop_epoch);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* ds = (float*)smem_raw;            // [N] dp -> ds
   float* red = ds + ((N + 3) & ~3);
@@ -285,7 +287,8 @@ extern "C" int xvit_cls_xattn_fwd(const void* q, int64_t ldq, const float* q_f32
     attr = lds;
   }
   hipLaunchKernelGGL(cls_xattn_fwd_kernel, dim3(H, B), dim3(XA_THREADS), lds, (hipStream_t)stream, (const bf16*)q, ldq, q_f32, ldqf, (const bf16*)k,
-                     (const bf16*)v, sb, sn, (bf16*)o, ldo, o_f32, ldof, p, H, N, scale, drop_p, drop_seed);
+                     (const bf16*)v, sb, sn, (bf16*)o, ldo, o_f32, ldof, p, H, N, scale, drop_p, drop_seed,
+                     drop_p > 0.f ? drop_epoch_ptr() : nullptr);
   return check_launch("xvit_cls_xattn_fwd");
 }
 
@@ -305,7 +308,8 @@ extern "C" int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, con
     attr = lds;
   }
   hipLaunchKernelGGL(cls_xattn_bwd_kernel, dim3(H, B), dim3(XA_THREADS), lds, (hipStream_t)stream, (const bf16*)q, ldq, (const bf16*)k, (const bf16*)v, sb,
-                     sn, p, (const bf16*)d_o, lddo, dq, lddq, (bf16*)dk, (bf16*)dv, coef, H, N, scale, drop_p, drop_seed);
+                     sn, p, (const bf16*)d_o, lddo, dq, lddq, (bf16*)dk, (bf16*)dv, coef, H, N, scale, drop_p, drop_seed,
+                     drop_p > 0.f ? drop_epoch_ptr() : nullptr);
   return check_launch("xvit_cls_xattn_bwd");
 }
 

@@ -28,6 +28,7 @@ struct GemmParams {
   float* slab;          // split-K partial sums [split][batch][M][N], else nullptr
   float* colsum;        // optional [N] fp32: += column sums of the stored C
   float drop_p, drop_inv; uint64_t drop_seed;   // dropout after the activation, before the residual (p == 0: off)
+  const uint64_t* drop_epoch;                   // device-side epoch added to the seed at run time (captured steps), or nullptr
   int aux_deriv;                 // aux holds GELU'(z) instead of z: ACT_GELU writes the derivative, ACT_DGELU multiplies by it
   int narrow_epi;                // force the 8-byte-per-lane epilogue (A/B measurements)
   int ncg;                       // gemm_big_kernel: column tiles per super-column of the tile walk
@@ -120,8 +121,9 @@ __device__ __forceinline__ f32x4 epilogue_apply(const GemmParams& p, f32x4 v, in
   if (DROP) {   // mask keyed by (seed, batch-local element index): regenerated, never stored
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
     const uint64_t idx = (uint64_t)(cb / (p.sC ? p.sC : 1)) * ((uint64_t)p.M * p.N) + (uint64_t)row * p.N + col;
+    const uint64_t seed = drop_seed_at(p.drop_seed, p.drop_epoch);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = (hash32(p.drop_seed, idx + e) & 0xFFFFFFu) >= thr ? v[e] * p.drop_inv : 0.f;
+    for (int e = 0; e < 4; ++e) v[e] = (hash32(seed, idx + e) & 0xFFFFFFu) >= thr ? v[e] * p.drop_inv : 0.f;
   }
   if (res) {
     const int rr = p.res_row_mod > 0 ? p.res_row_off + (row % p.res_row_mod) : row;
@@ -648,7 +650,7 @@ __device__ __forceinline__ void big_epi_body(const GemmParams& p, BigEpi& e, f32
       const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
       const uint64_t idx = e.drop_base + (uint64_t)e.row * p.N + e.col;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = (hash32(p.drop_seed, idx + c) & 0xFFFFFFu) >= thr ? v[c] * p.drop_inv : 0.f;
+      for (int c = 0; c < 4; ++c) v[c] = (hash32(drop_seed_at(p.drop_seed, p.drop_epoch), idx + c) & 0xFFFFFFu) >= thr ? v[c] * p.drop_inv : 0.f;
     }
     if (e.has_res) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(e.rres, ok ? e.res : OOB, 0, XVIT_EPI_RES_AUX));
     if (p.c_f32) {
@@ -775,7 +777,7 @@ __device__ __forceinline__ void wide_half(const GemmParams& p, f32x4& v, const b
   if (DROP) {
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = (hash32(p.drop_seed, idx + c) & 0xFFFFFFu) >= thr ? v[c] * p.drop_inv : 0.f;
+    for (int c = 0; c < 4; ++c) v[c] = (hash32(drop_seed_at(p.drop_seed, p.drop_epoch), idx + c) & 0xFFFFFFu) >= thr ? v[c] * p.drop_inv : 0.f;
   }
 }
 
@@ -1192,6 +1194,7 @@ extern "C" int xvit_gemm(const xvit_gemm_args* a, xvit_stream_t stream) {
   p.colsum = a->colsum;
   XVIT_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "xvit_gemm: dropout_p must be in [0, 1)");
   p.drop_p = a->dropout_p; p.drop_inv = 1.0f / (1.0f - a->dropout_p); p.drop_seed = a->dropout_seed;
+  p.drop_epoch = a->dropout_p > 0.f ? drop_epoch_ptr() : nullptr;
   p.narrow_epi = g_gemm_epi.load(std::memory_order_relaxed);
   p.aux_deriv = a->aux_mode;
   p.ncg = 1;
@@ -1303,7 +1306,7 @@ static void pe_defaults(GemmParams& p) {
   p.sA = p.sB = p.sC = p.sBias = p.sR = p.sAux = 0;
   p.c_f32 = 1; p.act = XVIT_ACT_NONE; p.accumulate = 0;
   p.res_row_mod = 0; p.res_row_off = 0; p.seg_rows = 0; p.seg_skip = 0; p.row_off = 0;
-  p.drop_p = 0.f; p.drop_inv = 1.f; p.drop_seed = 0; p.narrow_epi = 1; p.split_k = 1; p.aux_deriv = 0;
+  p.drop_p = 0.f; p.drop_inv = 1.f; p.drop_seed = 0; p.drop_epoch = nullptr; p.narrow_epi = 1; p.split_k = 1; p.aux_deriv = 0;
 }
 
 static void pe_attrs() {

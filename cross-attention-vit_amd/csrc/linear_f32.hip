@@ -23,7 +23,7 @@ struct F32Params {
   bf16* c_bf16; bf16* z_bf16;
   int64_t lda, ldw, ldc, ldr, ldcb, ldzb;
   int M, N, K, k_per_split, split_k, act;
-  float drop_p, drop_inv; uint64_t drop_seed;
+  float drop_p, drop_inv; uint64_t drop_seed; const uint64_t* drop_epoch;
 };
 
 __device__ __forceinline__ void f32_epilogue(const F32Params& p, float v, int row, int col) {
@@ -34,7 +34,7 @@ __device__ __forceinline__ void f32_epilogue(const F32Params& p, float v, int ro
   }
   if (p.drop_p > 0.f) {   // the mask of xvit_dropout on a contiguous [M, N] tensor with this seed
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
-    v = (hash32(p.drop_seed, (uint64_t)row * p.N + col) & 0xFFFFFFu) >= thr ? v * p.drop_inv : 0.f;
+    v = (hash32(drop_seed_at(p.drop_seed, p.drop_epoch), (uint64_t)row * p.N + col) & 0xFFFFFFu) >= thr ? v * p.drop_inv : 0.f;
   }
   if (p.res) v += p.res[(int64_t)row * p.ldr + col];
   p.C[(int64_t)row * p.ldc + col] = v;
@@ -120,7 +120,7 @@ extern "C" int xvit_linear_f32(const float* x, int64_t ldx, const float* W, int6
   p.M = M; p.N = N; p.K = K; p.act = act;
   p.split_k = f32_split(M, N, K);
   p.k_per_split = (((K + 15) / 16 + p.split_k - 1) / p.split_k) * 16;
-  p.drop_p = dropout_p; p.drop_inv = 1.0f / (1.0f - dropout_p); p.drop_seed = dropout_seed;
+  p.drop_p = dropout_p; p.drop_inv = 1.0f / (1.0f - dropout_p); p.drop_seed = dropout_seed; p.drop_epoch = dropout_p > 0.f ? drop_epoch_ptr() : nullptr;
   const int64_t need = xvit_linear_f32_workspace_bytes(M, N, K);
   XVIT_REQUIRE(need == 0 || (workspace && workspace_bytes >= need), "xvit_linear_f32: needs %lld bytes of workspace (got %lld)", (long long)need,
                (long long)workspace_bytes);

@@ -145,7 +145,8 @@ __global__ void colsum_reduce_kernel(const float* __restrict__ part, float* __re
 }
 
 template <typename T>
-__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, float inv_keep, uint64_t seed) {
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, float p, float inv_keep, uint64_t seed_in, const uint64_t* __restrict__ epoch) {
+  const uint64_t seed = drop_seed_at(seed_in, epoch);
   const uint32_t thr = (uint32_t)(p * 16777216.0f);  // drop when the 24-bit hash < p * 2^24
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const bool keep = (hash32(seed, (uint64_t)i) & 0xFFFFFFu) >= thr;
@@ -322,8 +323,8 @@ extern "C" int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, 
 extern "C" int xvit_dropout(const void* x, void* y, int dtype, int64_t n, float p, uint64_t seed, xvit_stream_t stream) {
   XVIT_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "xvit_dropout: bad arguments");
   const float inv = 1.0f / (1.0f - p);
-  if (dtype == XVIT_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, p, inv, seed);
-  else hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n, p, inv, seed);
+  if (dtype == XVIT_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, p, inv, seed, drop_epoch_ptr());
+  else hipLaunchKernelGGL((dropout_kernel<bf16>), dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)y, n, p, inv, seed, drop_epoch_ptr());
   return check_launch("xvit_dropout");
 }
 

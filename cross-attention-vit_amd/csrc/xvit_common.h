@@ -25,6 +25,7 @@ constexpr int kWave = 64;
 // ---- error plumbing (host) -----------------------------------------------------------
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+const uint64_t* drop_epoch_ptr();   // xvit_set_dropout_epoch: device address of the dropout epoch counter, or nullptr (core.hip)
 void set_attn_peel(int v);   // xvit_set_option("attn_peel") -> attention.hip
 
 #define XVIT_REQUIRE(cond, ...)            \
@@ -198,6 +199,13 @@ __device__ __forceinline__ uint32_t hash32(uint64_t seed, uint64_t idx) {
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
+
+// A captured step (HIP graph) freezes every kernel argument, the dropout seeds included.  A launch may therefore carry the device address
+// of an epoch counter (xvit_set_dropout_epoch): the seed a kernel then uses is seed + epoch * odd constant, read at run time, so that a
+// replay whose graph increments the counter first draws new masks — the same ones in its forward and its backward.
+__device__ __forceinline__ uint64_t drop_seed_at(uint64_t seed, const uint64_t* __restrict__ epoch) {
+  return epoch ? seed + *epoch * 0xD1B54A32D192ED03ull : seed;
 }
 
 }  // namespace xvit

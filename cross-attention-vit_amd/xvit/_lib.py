@@ -62,6 +62,7 @@ SIGNATURES = {
     "xvit_mean_ce": [vp, vp, f32, vp, vp, vp, i32, i32, i32, vp],
     "xvit_resize_pad_crop_i16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, f32, vp],
     "xvit_set_option": [C.c_char_p, i32],
+    "xvit_set_dropout_epoch": [C.c_void_p],
     "xvit_adam_step": [vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string", "xvit_gemm_workspace_bytes", "xvit_linear_f32_workspace_bytes",

@@ -10,8 +10,10 @@ graph's private pool.
     logits, loss = step(img, labels)                         # copies into the static inputs, replays; p.grad are filled
     optimizer.step()                                         # outside the graph
 
-Restrictions: static shapes; dropout must be inactive (masks are seeded on the host per call, a replay would repeat
-them).  The per-modality self-attention branches and the fusions fork from and join back into the capture stream, so the
+Restrictions: static shapes.  Dropout (the reference trains with p = 0.1 .. 0.25, main_mist.py:71-77): the host-side seeds of the
+capture are frozen into the graph, so the step registers a device counter (xvit_set_dropout_epoch), increments it at the head of the
+graph, and every dropout kernel mixes its value into the seed at run time: each replay draws fresh masks, the same in its forward and
+its backward.  The per-modality self-attention branches and the fusions fork from and join back into the capture stream, so the
 graph keeps them as parallel paths (XVIT_GRAPH_STREAMS=branches forks the branches only, =0 captures on one stream).
 
 The captured step runs the model on detached leaf ALIASES of its parameters (torch.func.functional_call; same storage, so
@@ -31,6 +33,11 @@ import torch
 from . import functional as XF
 
 
+def _has_dropout(model) -> bool:
+    """Any active rate on the path (the module facades keep their rates in nn.Dropout children, like the reference)."""
+    return any(isinstance(m, torch.nn.Dropout) and m.p > 0 for m in model.modules())
+
+
 class GraphedStep:
     """reducer (xvit.ddp.BucketedGradReducer, optional): data-parallel runs.  The reducer's bucket views become the gradient buffers
     (weight-gradient kernels write into them, functional.GRAD_SINK) and its bucket all-reduces are captured INTO the graph, each
@@ -40,9 +47,8 @@ class GraphedStep:
     def __init__(self, model, img, labels, warmup: int = 3, reducer=None):
         if not img.is_cuda:
             raise RuntimeError("GraphedStep needs GPU tensors")
-        for m in model.modules():
-            if isinstance(m, torch.nn.Dropout) and m.p > 0 and model.training:
-                raise RuntimeError("GraphedStep: dropout is active; its host-side seeds cannot be captured (use p = 0 or eval)")
+        # dropout active anywhere in the step: a device-side epoch makes every replay draw new masks (module docstring)
+        self._epoch = torch.zeros(1, dtype=torch.int64, device=img.device) if model.training and _has_dropout(model) else None
         if os.environ.get("XVIT_FANOUT", "1") != "1" and os.environ.get("XVIT_GRAPH_STREAMS", "1") == "1":
             # without the fan-out node a branch output read by two forked fusions has its gradients accumulated by the autograd
             # engine ACROSS the side streams: exactly the pattern hipStreamEndCapture crashes on (tools/graph_capture_probe.py)
@@ -103,6 +109,17 @@ class GraphedStep:
             for p in self.params:
                 p.grad = None
         XF.SHADOWS.force = True                # the captured step always re-casts the weights (they change every step)
+        if self._epoch is None:
+            return self._step()
+        from . import ops
+        ops.set_dropout_epoch(self._epoch)     # process-wide while this step is being issued (warm-up and capture); off again below
+        try:
+            self._epoch.add_(1)                # first node of the graph: a new epoch per replay
+            return self._step()
+        finally:
+            ops.set_dropout_epoch(None)
+
+    def _step(self):
         red = self.reducer
         if red is None:
             logits, loss = torch.func.functional_call(self.model, self._alias, (self.img, self.labels))

@@ -45,6 +45,21 @@ def set_option(name: str, value: int):
     _lib.check(_lib.load().xvit_set_option(name.encode(), int(value)), "xvit_set_option")
     if name == "gemm_tile":
         GEMM_TILE = int(value)
+
+
+_DROP_EPOCH = None       # keeps the registered counter tensor alive
+
+
+def set_dropout_epoch(counter):
+    """xvit_set_dropout_epoch (include/xvit.h): register a one-element int64 device tensor whose value is mixed into every dropout seed at
+    kernel run time (captured steps: xvit.graph.GraphedStep increments it at the head of its graph), or None to switch it off."""
+    global _DROP_EPOCH
+    if counter is not None and not (counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
+        raise RuntimeError("set_dropout_epoch: need a one-element int64 GPU tensor (or None)")
+    _lib.check(_lib.load().xvit_set_dropout_epoch(counter.data_ptr() if counter is not None else None), "xvit_set_dropout_epoch")
+    _DROP_EPOCH = counter
+
+
 PROFILE_SHAPES = False   # append the GEMM shape/epilogue to the family name (bench.py --detail)
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define XVIT_VERSION 300 /* 0.3.0: workspaces in xvit_attn_fwd/bwd (CLS peel), xvit_linear_f32_batched; 0.2.0: ld_alt in xvit_layernorm_fwd/bwd, dropout in xvit_attn_*, xvit_patch_embed_*, xvit_attn_fwd_fp8, xvit_linear_f32, workspaces */
+#define XVIT_VERSION 301 /* 0.3.1: xvit_set_dropout_epoch; 0.3.0: workspaces in xvit_attn_fwd/bwd (CLS peel), xvit_linear_f32_batched; 0.2.0: ld_alt in xvit_layernorm_fwd/bwd, dropout in xvit_attn_*, xvit_patch_embed_*, xvit_attn_fwd_fp8, xvit_linear_f32, workspaces */
 
 enum { XVIT_OK = 0, XVIT_ERR_ARG = -1, XVIT_ERR_UNSUPPORTED = -2 };
 enum { XVIT_BF16 = 0, XVIT_F32 = 1 };
@@ -40,6 +40,12 @@ const char* xvit_last_error_string(void);
  *   "gemm_group"     0 = automatic, n > 0 = column tiles per super-column of the 256x256 kernel's tile walk
  *   "gemm_epilogue"  0 = automatic, 1 = always the 8-byte-per-lane epilogue (bf16 outputs normally use 16 bytes per lane) */
 int xvit_set_option(const char* name, int value);
+/* Dropout under HIP-graph capture.  The reference seeds its dropout masks from the host RNG at every call (nn.Dropout,
+ * model_cross.py:27,47,95,101,170; it trains with p = 0.1 .. 0.25, main_mist.py:71-77); a captured step would freeze the seeds passed
+ * below and replay the same masks.  With a device counter registered here (process-wide; NULL = off, the default) every dropout-carrying
+ * launch hands its address to the kernel, which uses seed + counter * odd constant, read at run time: a graph that increments the counter
+ * at its head draws fresh masks at every replay, identical in its forward and backward.  Results with NULL are unchanged. */
+int xvit_set_dropout_epoch(const uint64_t* device_counter);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM with fused epilogue.  Replaces every nn.Linear on the path and its autograd backward:

@@ -104,3 +104,56 @@ def test_graphed_step_replays_with_new_inputs_on_forked_fusions(name, batch):
         for k, p in model.named_parameters():
             ref = refs[which][1][k]
             assert rel(p.grad, ref) < 1e-5 or float(ref.abs().max()) < 1e-6, (which, k, rel(p.grad, ref))
+
+
+def test_graphed_step_with_dropout_draws_new_masks_per_replay_and_matches_eager_at_the_same_epoch():
+    """The reference trains with dropout 0.1 .. 0.25 (main_mist.py:71-77).  A captured step freezes the host-side seeds; the device-side
+    epoch (xvit_set_dropout_epoch) makes each replay draw new masks.  Checked: (1) two replays of the same input differ; (2) a replay is
+    exactly the eager step issued with the same host seeds and the same epoch value — logits, loss and every gradient; (3) eval mode and
+    eager training afterwards are untouched (the registration is gone)."""
+    import xvit
+    import xvit.functional as XF
+    from xvit import ops
+    from xvit.graph import GraphedStep
+    cfg = R.make_config("tiny", dropout=0.25)
+    model = xvit.ModelCross(cfg).to(dev())
+    model.load_state_dict(R.make_state_dict(cfg, seed=0))
+    model.train()
+    img, lab = R.make_inputs(cfg, 4, seed=0)
+    img, lab = img.to(dev()), lab.to(dev())
+    torch.manual_seed(123)
+    calls0 = XF._DROP_CALLS
+    step = GraphedStep(model, img, lab, warmup=2)
+    per_step = (XF._DROP_CALLS - calls0) // 3            # 2 warm-up steps + the capture drew seeds
+    assert per_step > 0 and ops._DROP_EPOCH is None
+    capture_calls = XF._DROP_CALLS - per_step            # the call counter the captured step started from
+    assert int(step._epoch) == 2                         # the capture itself executes nothing
+    l1, loss1 = step()
+    l1, loss1 = l1.clone(), float(loss1)
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    l2, loss2 = step()
+    torch.cuda.synchronize()
+    assert int(step._epoch) == 4 and not torch.equal(l1, l2) and float(loss2) != loss1       # (1) fresh masks
+    # (2) the eager step with the capture's host seeds at epoch 3 (= the first replay)
+    epoch = torch.full((1,), 3, dtype=torch.int64, device=dev())
+    XF._DROP_CALLS = capture_calls
+    ops.set_dropout_epoch(epoch)
+    try:
+        for p in model.parameters():
+            p.grad = None
+        le, losse = model(img, lab)
+        losse.backward()
+    finally:
+        ops.set_dropout_epoch(None)
+    assert torch.equal(le.detach(), l1) and float(losse.detach()) == loss1
+    for k, p in model.named_parameters():
+        assert rel(p.grad, g1[k]) < 1e-5 or float(g1[k].abs().max()) < 1e-6, k
+    # the masks are real: the same seeds WITHOUT the epoch give another result
+    XF._DROP_CALLS = capture_calls
+    l0, _ = model(img, lab)
+    assert not torch.equal(l0.detach(), l1)
+    # (3) eval mode has no dropout: deterministic, equal to the p = 0 model
+    model.eval()
+    a, _ = model(img, lab)
+    b, _ = model(img, lab)
+    assert torch.equal(a, b)
