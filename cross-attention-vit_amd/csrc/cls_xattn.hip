@@ -158,7 +158,7 @@ __global__ __launch_bounds__(XA_THREADS) void cls_xattn_bwd_kernel(const bf16* _
       *(bf16x8*)(dv + boff + (int64_t)n * sn + part * 8) = ovv;
     }
     // dK and dV of this (b, head) are rank one — dk[n] = dsn q, dv[n] = pr dO: the two coefficients are all the K/V path's
-    // backward needs (xattn_kv_dgrad_kernel / xattn_kv_wgrad_kernel below), coef[b][n][head] = dsn, coef[b][n][H + head] = pr
+    // backward needs (xattn_kv_dgrad_kernel below), coef[b][n][head] = dsn, coef[b][n][H + head] = pr
     if (coef && part == 0) {
       float* c = coef + ((int64_t)b * N + n) * (2 * H);
       c[head] = dsn;
@@ -229,42 +229,6 @@ __global__ __launch_bounds__(256) void xattn_kv_dgrad_kernel(const float* __rest
   }
 }
 
-template <int J2>
-__global__ __launch_bounds__(256) void xattn_kv_wgrad_kernel(const float* __restrict__ coef, const bf16* __restrict__ hn, int64_t ldh,
-                                                             float* __restrict__ part /*[slices][2 H][B][d]*/, int H, int N, int d, int rows_per_block) {
-  __shared__ __attribute__((aligned(16))) float cl[XKV_ROWS * J2];
-  const int b = blockIdx.y, tid = threadIdx.x, J = 2 * H;
-  const int n0 = blockIdx.x * rows_per_block, n1 = min(N, n0 + rows_per_block);
-  const int c0 = 4 * tid;
-  f32x4 T[J2];
-#pragma unroll
-  for (int j = 0; j < J2; ++j) T[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int nb = n0; nb < n1; nb += XKV_ROWS) {
-    const int rows = min(XKV_ROWS, n1 - nb);
-    __syncthreads();
-    xkv_stage<J2>(cl, coef, (int64_t)b * N + nb, rows, J);
-    __syncthreads();
-    if (c0 < d) {
-      bf16x4 hv = *(const bf16x4*)(hn + ((int64_t)b * N + nb) * ldh + c0);
-      for (int rr = 0; rr < rows; ++rr) {
-        const f32x4 x = {bf2f(hv[0]), bf2f(hv[1]), bf2f(hv[2]), bf2f(hv[3])};
-        if (rr + 1 < rows) hv = *(const bf16x4*)(hn + ((int64_t)b * N + nb + rr + 1) * ldh + c0);   // next row in flight under the fmas
-#pragma unroll
-        for (int j4 = 0; j4 < J2; j4 += 4) {
-          const f32x4 cf = *(const f32x4*)(cl + rr * J2 + j4);
-          T[j4] += cf[0] * x; T[j4 + 1] += cf[1] * x; T[j4 + 2] += cf[2] * x; T[j4 + 3] += cf[3] * x;
-        }
-      }
-    }
-  }
-  if (c0 < d) {
-    float* dst = part + (((int64_t)blockIdx.x * J) * gridDim.y + b) * d + c0;
-#pragma unroll
-    for (int j = 0; j < J2; ++j)
-      if (j < J) *(f32x4*)(dst + (int64_t)j * gridDim.y * d) = T[j];
-  }
-}
-
 }  // namespace xvit
 
 using namespace xvit;
@@ -331,23 +295,4 @@ extern "C" int xvit_xattn_kv_dgrad(const float* coef, const float* R, void* dhn,
   else if (2 * H <= 24) hipLaunchKernelGGL((xattn_kv_dgrad_kernel<24>), grid, block, 0, s, coef, R, (bf16*)dhn, lddh, H, N, d, rpb);
   else hipLaunchKernelGGL((xattn_kv_dgrad_kernel<32>), grid, block, 0, s, coef, R, (bf16*)dhn, lddh, H, N, d, rpb);
   return check_launch("xvit_xattn_kv_dgrad");
-}
-
-extern "C" int64_t xvit_xattn_kv_wgrad_partials(int B, int H, int N, int d) {   // floats in `part`: [slices][2 H][B][d]
-  if (B <= 0 || H <= 0 || N <= 0 || d <= 0) return 0;
-  return (int64_t)B * xkv_slices(B, N, 512) * 2 * H * d;
-}
-
-extern "C" int xvit_xattn_kv_wgrad(const float* coef, const void* hn, int64_t ldh, float* part, int B, int H, int N, int d, xvit_stream_t stream) {
-  XVIT_REQUIRE(coef && hn && part, "xvit_xattn_kv_wgrad: null pointer");
-  XVIT_REQUIRE(B > 0 && B <= 65535 && N > 0 && H > 0 && 2 * H <= XKV_MAXJ && d % 4 == 0 && d <= 1024, "xvit_xattn_kv_wgrad: need 2 H <= %d, d %% 4 == 0 and d <= 1024 (B=%d H=%d N=%d d=%d)", XKV_MAXJ, B, H, N, d);
-  XVIT_REQUIRE(ldh % 4 == 0 && ldh >= d && ((uintptr_t)hn & 7) == 0 && ((uintptr_t)part & 15) == 0, "xvit_xattn_kv_wgrad: ldh must be a multiple of 4 and >= d, pointers aligned");
-  const int slices = xkv_slices(B, N, 512), rpb = (N + slices - 1) / slices;
-  const dim3 grid(slices, B), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (2 * H <= 8) hipLaunchKernelGGL((xattn_kv_wgrad_kernel<8>), grid, block, 0, s, coef, (const bf16*)hn, ldh, part, H, N, d, rpb);
-  else if (2 * H <= 16) hipLaunchKernelGGL((xattn_kv_wgrad_kernel<16>), grid, block, 0, s, coef, (const bf16*)hn, ldh, part, H, N, d, rpb);
-  else if (2 * H <= 24) hipLaunchKernelGGL((xattn_kv_wgrad_kernel<24>), grid, block, 0, s, coef, (const bf16*)hn, ldh, part, H, N, d, rpb);
-  else hipLaunchKernelGGL((xattn_kv_wgrad_kernel<32>), grid, block, 0, s, coef, (const bf16*)hn, ldh, part, H, N, d, rpb);
-  return check_launch("xvit_xattn_kv_wgrad");
 }

@@ -42,12 +42,12 @@ SIGNATURES = {
     "xvit_cls_xattn_fwd": [vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, vp, i64, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_cls_xattn_bwd": [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i64, vp, vp, vp, i32, i32, i32, i32, f32, f32, u64, vp],
     "xvit_head_rows": [vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp],
-    "xvit_head_cols": [vp, i64, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i32, i32, i32, vp],
+    "xvit_head_cols": [vp, i64, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp],
+    "xvit_head_bias_grad": [vp, i64, vp, i64, vp, i32, i32, i32, vp],
     "xvit_head_wgrad": [vp, i64, vp, i64, i64, vp, i64, vp, i64, i32, i32, i32, vp],
-    "xvit_cls_softmax_fwd": [vp, i64, vp, i64, vp, i32, i32, i32, f32, vp],
-    "xvit_cls_softmax_bwd": [vp, i64, vp, vp, i64, vp, vp, i64, i32, i32, i32, f32, vp],
+    "xvit_cls_softmax_fwd": [vp, i64, vp, i64, vp, i32, i32, i32, f32, vp, f32, u64, vp],
+    "xvit_cls_softmax_bwd": [vp, i64, vp, vp, i64, vp, vp, i64, i32, i32, i32, f32, f32, u64, vp],
     "xvit_xattn_kv_dgrad": [vp, vp, vp, i64, i32, i32, i32, i32, vp],
-    "xvit_xattn_kv_wgrad": [vp, vp, i64, vp, i32, i32, i32, i32, vp],
     "xvit_patchify": [vp, i32, vp, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, i32, i64, vp],
     "xvit_patch_embed_supported": [C.POINTER(PatchGeom), i32],
     "xvit_patch_embed_fwd": [vp, C.POINTER(PatchGeom), vp, i64, vp, vp, i64, vp, i64, i32, vp],
@@ -66,7 +66,7 @@ SIGNATURES = {
     "xvit_adam_step": [vp, vp, i32, f32, f32, f32, f32, f32, i32, f32, vp],
 }
 EXPORTS = sorted(list(SIGNATURES) + ["xvit_version", "xvit_last_error_string", "xvit_gemm_workspace_bytes", "xvit_linear_f32_workspace_bytes",
-                                    "xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes", "xvit_patch_embed_wgrad_workspace_bytes", "xvit_attn_fp8_workspace_bytes", "xvit_xattn_kv_wgrad_partials",
+                                    "xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes", "xvit_patch_embed_wgrad_workspace_bytes", "xvit_attn_fp8_workspace_bytes",
                                     "xvit_attn_fwd_workspace_bytes", "xvit_attn_bwd_workspace_bytes"])
 
 _lib = None
@@ -91,8 +91,6 @@ def load() -> C.CDLL:
         for name in ("xvit_colsum_workspace_bytes", "xvit_layernorm_bwd_workspace_bytes"):
             getattr(lib, name).argtypes = [i32, i32]
             getattr(lib, name).restype = C.c_int64
-        lib.xvit_xattn_kv_wgrad_partials.argtypes = [i32, i32, i32, i32]
-        lib.xvit_xattn_kv_wgrad_partials.restype = C.c_int64
         lib.xvit_attn_fp8_workspace_bytes.argtypes = [i32, i32, i32, i32]
         lib.xvit_attn_fp8_workspace_bytes.restype = C.c_int64
         for name in ("xvit_attn_fwd_workspace_bytes", "xvit_attn_bwd_workspace_bytes"):

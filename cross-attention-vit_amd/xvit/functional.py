@@ -353,16 +353,21 @@ def _f32c(t):
 # The all-token FFNs save gelu'(pre-activation) instead of the pre-activation itself (xvit_gemm aux_mode 1): the forward epilogue
 # has the exponential at hand anyway, and the GELU' dgrad epilogue becomes a multiply.  XVIT_GELU_AUX=z restores the old form.
 AUX_MODE = 0 if os.environ.get("XVIT_GELU_AUX", "deriv") == "z" else 1
-XATTN_LOWRANK = os.environ.get("XVIT_XATTN_LOWRANK", "1") == "1"
-# The fusion's K/V path: "lowrank" (default) never applies wk / wv to the N tokens (xvit_head_* + two batched GEMMs over hn, see
+# The fusion's K/V path: "lowrank" never applies wk / wv to the N tokens (xvit_head_* + two batched GEMMs over hn, see
 # csrc/head_linear.hip); "dense" is the reference's literal order (kv = hn Wkv^T + b, then the CLS-query attention kernel).
-XATTN_FORM = os.environ.get("XVIT_XATTN_FORM", "lowrank")
+# "auto" (default): low-rank wherever the GPU is the bound — XATTN_AUTO_ROWS token rows or more, or a step being captured into a HIP
+# graph — and the literal order on small eager batches, which are bound by the host: it is 15 launches per fusion instead of 22
+# (the reference's run shape at batch 8, eager: 13.0 vs 14.7 ms per step; captured: 8.59 vs 8.44 — tools/config_step_bench.py mist).
+XATTN_FORM = os.environ.get("XVIT_XATTN_FORM", "auto")
+XATTN_AUTO_ROWS = 8192
 
 
-def _xattn_lowrank_ok(H, d, p):
-    """Shapes the low-rank form is built for (otherwise the dense form runs): 64-wide heads, H <= 16 (one 16-column operand),
-    no dropout on the probabilities (with it the weights in front of bv no longer sum to one)."""
-    return XATTN_FORM == "lowrank" and XATTN_LOWRANK and p == 0.0 and d == 64 * H and H <= 16 and d <= 1024
+def _xattn_lowrank_ok(H, d, rows):
+    """Shapes the low-rank form is built for (otherwise the dense form runs): 64-wide heads, H <= 16 (one 16-column operand).  Dropout on
+    the probabilities is part of it (the kept weights feed the row sums; bv is weighted by their sum: csrc/head_linear.hip)."""
+    if XATTN_FORM == "dense" or not (d == 64 * H and H <= 16 and d <= 1024):
+        return False
+    return XATTN_FORM == "lowrank" or rows >= XATTN_AUTO_ROWS or torch.cuda.is_current_stream_capturing()
 
 
 def _attn_fwd(qkv, B, N, H, scale, p=0.0, seed=0):
@@ -500,7 +505,7 @@ def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq, bq, wkv_s, bkv, wp, bp, 
     cls_in = xi if xi.shape[0] == B else xi.reshape(B, N * d)[:, :d]
     hn0f, _, _, _ = ops.layernorm_fwd_f32(cls_in, ln1w, ln1b, eps, want_bf16=False)
     qf, qb, _ = ops.linear_f32(hn0f, wq, bq, want_bf16=True)
-    lowrank = wk is not None and _xattn_lowrank_ok(H, d, p)
+    lowrank = wk is not None and _xattn_lowrank_ok(H, d, B * N)
     if lowrank:
         # scores = hn . (q_h Wk_h), out = Wv_h (sum_n p hn) + bv: wk / wv meet one row per (sample, head), never the N tokens
         hn3 = hn.view(B, N, d)
@@ -509,10 +514,15 @@ def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq, bq, wkv_s, bkv, wp, bp, 
         ops.head_rows(qf, wk, R[:H].transpose(0, 1), H, out_bf16=Ub)
         sc = torch.empty(B, N, 16, dtype=torch.float32, device=xi.device)
         ops.gemm(ops.NT, hn3, Ub, sc)                                              # [N, d] x [d, 16] per sample
-        e, rz = ops.cls_softmax_fwd(sc, H, scale)
         S = torch.empty(B, 16, d, dtype=torch.float32, device=xi.device)
-        ops.gemm(ops.TN, e, hn3, S)                                                # [16, N] x [N, d] per sample
-        ocf, oc = ops.head_cols(S, wv, H, row_scale=rz, bias=bv, want_bf16=True)
+        if p > 0.0:   # attn_drop (model_cross.py:97): the row sums run over the KEPT weights; stat = (rz, rz / (1 - p), that times their sum)
+            e, rz, ek = ops.cls_softmax_fwd(sc, H, scale, dropout=(p, seeds[0]))
+            ops.gemm(ops.TN, ek, hn3, S)
+            ocf, oc = ops.head_cols(S, wv, H, row_scale=rz[1], bias=bv, bias_scale=rz[2], want_bf16=True)
+        else:
+            e, rz = ops.cls_softmax_fwd(sc, H, scale)
+            ops.gemm(ops.TN, e, hn3, S)                                            # [16, N] x [N, d] per sample
+            ocf, oc = ops.head_cols(S, wv, H, row_scale=rz, bias=bv, want_bf16=True)
         kv, pr = (R, e, rz, S, qf), None                                           # what the backward needs instead of kv / p
     else:
         kv = _linear(hn, wkv_s, bias=bkv)
@@ -564,28 +574,24 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
         ops.head_rows(doc, wv, R[H:].transpose(0, 1), H, out_bf16=Yb)             # Y[b, h] = dO_h Wv_h: dp[b, n, h] = hn[b, n] . Y[b, h]
         dp = torch.empty(B, N, 16, dtype=torch.float32, device=xi.device)
         ops.gemm(ops.NT, hn3, Yb, dp)
-        coef, dsb = ops.cls_softmax_bwd(e, rz, dp, H, scale)                       # (ds | p) per token and head
+        drop = pd > 0.0                                                            # rz is then the forward's stat block (rz, rz / (1 - p), bv's weight)
+        coef, dsb = ops.cls_softmax_bwd(e, rz[0] if drop else rz, dp, H, scale, dropout=(pd, seeds[0]))   # (ds | p') per token and head
         dhn = ops.xattn_kv_dgrad(coef, R, B, N, H, d)                              # dhn[n] = sum_h ds U_h + p Y_h
         T = torch.empty(B, 16, d, dtype=torch.float32, device=xi.device)
         ops.gemm(ops.TN, dsb, hn3, T)                                              # T[b, h] = sum_n ds hn[b, n]
         dq, _ = ops.head_cols(T, wk, H)                                            # dq_h = Wk_h T_h  (the bk term carries sum_n ds = 0)
         g["wk"] = ops.head_wgrad(qf, T, H, out=_grad_out(wk, (d, d), xi.device))
-        g["wv"] = ops.head_wgrad(doc, S, H, row_scale=rz, out=_grad_out(wv, (d, d), xi.device))
-        g["bv"] = ops.colsum(doc)
+        g["wv"] = ops.head_wgrad(doc, S, H, row_scale=rz[1] if drop else rz, out=_grad_out(wv, (d, d), xi.device))
+        g["bv"] = ops.head_bias_grad(doc, rz[2], H) if drop else ops.colsum(doc)
         g["bk"] = bk0                                                              # analytically zero: sum_n ds[n] = 0
         return _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d, dy)
+    # the reference's literal order (XVIT_XATTN_FORM=dense, more than 16 heads, head widths other than 64): the K/V projection's
+    # gradient through the [B N, 2 d] tensor — a K = 2 d dgrad GEMM, a wgrad GEMM and a column-sum pass
     doc = _dgrad(dyb1, wp_s)
-    # dK / dV of one (b, head) are rank one (a coefficient per key times q_h resp. dO_h): with 2 H <= 32 the K/V projection's
-    # backward runs in that form — no [B N, 2 d] gradient tensor, no K = 2 d dgrad / wgrad GEMMs, no column-sum pass over it
-    # (XVIT_XATTN_LOWRANK=0: the dense form)
-    low_rank = XATTN_LOWRANK and 2 * H <= 32 and d == 64 * H and d <= 1024
-    dq, dkv = ops.cls_xattn_bwd(q, kv, p, doc, B, N, H, scale, dropout=(pd, seeds[0]), low_rank=low_rank)
-    if low_rank:
-        dhn, g["wkv"], g["bkv"] = ops.xattn_kv_backward(dkv, q, doc, wkv_s, hn, B, N, H)
-    else:
-        dhn = _dgrad(dkv, wkv_s)                            # [B*N, d] bf16
-        g["wkv"] = _wgrad(dkv, hn)
-        g["bkv"] = ops.colsum(dkv)
+    dq, dkv = ops.cls_xattn_bwd(q, kv, p, doc, B, N, H, scale, dropout=(pd, seeds[0]))
+    dhn = _dgrad(dkv, wkv_s)                                # [B*N, d] bf16
+    g["wkv"] = _wgrad(dkv, hn)
+    g["bkv"] = ops.colsum(dkv)
     g["wk"], g["wv"] = g["wkv"].split(d, dim=0)
     g["bk"], g["bv"] = g["bkv"].split(d)
     return _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d, dy)

@@ -71,6 +71,9 @@ class GraphedStep:
         # "branches" only the self-attention branches, "0" captures everything on one stream.  Set as a context variable
         # (cross_vit.STREAM_MODE), not through os.environ: another thread's model keeps its own mode.
         from .cross_vit import STREAM_MODE
+        form = XF.XATTN_FORM
+        if form == "auto":
+            XF.XATTN_FORM = "lowrank"              # warm up the kernels the capture will run (auto picks them only while capturing)
         self._mode_token = STREAM_MODE.set({"0": "0", "branches": "branches"}.get(os.environ.get("XVIT_GRAPH_STREAMS", "1"), "1"))
         try:
             side = torch.cuda.Stream(device=img.device)
@@ -96,6 +99,7 @@ class GraphedStep:
             self._ptrs = [p.data_ptr() for p in self.params]
             self._flat = getattr(model, "_flat", None)
         finally:
+            XF.XATTN_FORM = form
             self._restore_env()                    # also when warm-up or capture raises: never leave the process in capture mode
 
     def _restore_env(self):

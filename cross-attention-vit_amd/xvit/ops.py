@@ -322,7 +322,7 @@ def cls_xattn_fwd(q, kv, B, N, H, scale, dropout=(0.0, 0), want_f32=False):
 
 def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale, dropout=(0.0, 0), low_rank=False):
     """-> (dq fp32 [B, d], dkv bf16 [B*N, 2d])   or, low_rank: (dq, coef fp32 [B, N, 2H]) with dk[n] = coef[.., h] q_h and
-    dv[n] = coef[.., H + h] dO_h (include/xvit.h): the input of xattn_kv_dgrad / xattn_kv_wgrad."""
+    dv[n] = coef[.., H + h] dO_h (include/xvit.h): the input of xattn_kv_dgrad."""
     d = q.shape[1]
     dq = torch.empty(B, d, dtype=torch.float32, device=q.device)
     ld = _rows2d(kv)
@@ -343,28 +343,6 @@ def cls_xattn_bwd(q, kv, p, d_o, B, N, H, scale, dropout=(0.0, 0), low_rank=Fals
     return dq, out
 
 
-def xattn_kv_backward(coef, q, d_o, wkv_b, hn, B, N, H):
-    """Low-rank backward of the fusion's K/V projection (kv = hn Wkv^T + bkv, model_cross.py:92-93) from the coefficients of
-    cls_xattn_bwd(low_rank=True): -> (dhn bf16 [B*N, d], dWkv fp32 [2d, d], dbkv fp32 [2d]).  q, d_o: bf16 [B, d] (the CLS query and
-    the gradient of the attention output); wkv_b: bf16 [2d, d]; hn: bf16 [B*N, d] (the normed tokens)."""
-    d = q.shape[1]
-    lib = _lib.load()
-    vec = torch.cat((q.view(B, H, d // H), d_o.view(B, H, d // H)), dim=1).float()      # [B, 2H, 64]: q_h, then dO_h
-    wf = wkv_b.float().view(2 * H, d // H, d)                                           # (wk | wv)[head][e][:]
-    R = torch.bmm(vec.transpose(0, 1), wf)                                              # [2H, B, d]: R[h] = q_h Wk_h, R[H + h] = dO_h Wv_h
-    dhn = torch.empty(B * N, d, dtype=torch.bfloat16, device=q.device)
-    _run("xattn_kv_dgrad", B * N * d * 2.0 + B * N * 2 * H * 4.0, "byte",
-         lambda: lib.xvit_xattn_kv_dgrad(_ptr(coef), _ptr(R), _ptr(dhn), d, B, H, N, d, _stream()), "xvit_xattn_kv_dgrad")
-    nfl = lib.xvit_xattn_kv_wgrad_partials(B, H, N, d)
-    part = torch.empty(nfl, dtype=torch.float32, device=q.device)
-    _run("xattn_kv_wgrad", B * N * d * 2.0 + B * N * 2 * H * 4.0, "byte",
-         lambda: lib.xvit_xattn_kv_wgrad(_ptr(coef), _ptr(hn), _rows2d(hn), _ptr(part), B, H, N, d, _stream()), "xvit_xattn_kv_wgrad")
-    T = part.view(-1, 2 * H, B, d).sum(0)                                               # [2H, B, d]: the row slices, in a fixed order
-    dW = torch.bmm(vec.permute(1, 2, 0), T).reshape(2 * d, d)                           # dWk[64 h + e, :] = sum_b q[b, h, e] T[h, b, :]; dWv likewise
-    db = (vec * coef.sum(1)[:, :, None]).sum(0).reshape(2 * d)                          # bias: the coefficients summed over the tokens
-    return dhn, dW, db
-
-
 def head_rows(x, W, out, H, out_bf16=None):
     """out[b, h, :] = x[b, 64h:64h+64] @ W[64h:64h+64, :] (xvit_head_rows; fp32, per head).  x fp32 [B, d]; W fp32 [d, d] (a master
     weight); out fp32 and out_bf16 (optional): any tensors indexable as [b, h, c] with a unit last stride — e.g. a [H, B, d] slab
@@ -380,15 +358,17 @@ def head_rows(x, W, out, H, out_bf16=None):
     return out
 
 
-def head_cols(t, W, H, row_scale=None, bias=None, want_bf16=False):
-    """out[b, 64h+e] = row_scale[b, h] * (t[b, h, :] . W[64h+e, :]) + bias[64h+e] (xvit_head_cols).  t fp32 [B, >=H, d] -> (fp32 [B, d], bf16 | None)."""
+def head_cols(t, W, H, row_scale=None, bias=None, want_bf16=False, bias_scale=None):
+    """out[b, 64h+e] = row_scale[b, h] * (t[b, h, :] . W[64h+e, :]) + bias_scale[b, h] * bias[64h+e] (xvit_head_cols).  t fp32 [B, >=H, d] -> (fp32 [B, d], bf16 | None)."""
     B, _, d = t.shape
     assert t.dtype == torch.float32 and t.stride(2) == 1 and W.dtype == torch.float32
+    assert bias_scale is None or (bias_scale.dtype == torch.float32 and bias_scale.stride(-1) == 1 and bias_scale.shape == (B, H))
     out = torch.empty(B, d, dtype=torch.float32, device=t.device)
     ob = torch.empty(B, d, dtype=torch.bfloat16, device=t.device) if want_bf16 else None
     _run("head_linear", 2.0 * B * d * 64, "flop",
          lambda: _lib.load().xvit_head_cols(_ptr(t), t.stride(0), t.stride(1), _ptr(W), _rows2d(W), _ptr(row_scale), row_scale.stride(0) if row_scale is not None else 0,
-                                            _ptr(bias), _ptr(out), d, _ptr(ob), d, B, H, d, _stream()), "xvit_head_cols")
+                                            _ptr(bias), _ptr(bias_scale), bias_scale.stride(0) if bias_scale is not None else 0, _ptr(out), d, _ptr(ob), d, B, H, d,
+                                            _stream()), "xvit_head_cols")
     return out, ob
 
 
@@ -404,24 +384,42 @@ def head_wgrad(x, t, H, row_scale=None, out=None):
     return dW
 
 
-def cls_softmax_fwd(s, H, scale):
-    """s fp32 [B, N, 16] (scores of the H heads in the first columns) -> (e bf16 [B, N, 16] = exp(scale (s - max_n s)), zero past H; rz fp32 [B, H] = 1 / sum_n e)."""
+def cls_softmax_fwd(s, H, scale, dropout=None):
+    """s fp32 [B, N, 16] (scores of the H heads in the first columns) -> (e bf16 [B, N, 16] = exp(scale (s - max_n s)), zero past H; rz fp32 [B, H] = 1 / sum_n e).
+    dropout = (p, seed) on the probabilities (model_cross.py:97): -> (e, stat fp32 [3, B, H] = (rz, rz / (1 - p), rz / (1 - p) * sum_n e_kept), e_kept bf16 [B, N, 16])."""
     B, N, ld = s.shape
     assert s.dtype == torch.float32 and s.is_contiguous() and ld == 16
     e = torch.empty(B, N, 16, dtype=torch.bfloat16, device=s.device)
-    rz = torch.empty(B, H, dtype=torch.float32, device=s.device)
-    _run("cls_softmax", B * N * 16 * 6.0, "byte", lambda: _lib.load().xvit_cls_softmax_fwd(_ptr(s), ld, _ptr(e), 16, _ptr(rz), B, H, N, scale, _stream()), "xvit_cls_softmax_fwd")
-    return e, rz
+    drop = dropout is not None and dropout[0] > 0.0
+    rz = torch.empty((3, B, H) if drop else (B, H), dtype=torch.float32, device=s.device)
+    em = torch.empty_like(e) if drop else None
+    _run("cls_softmax", B * N * 16 * 6.0, "byte",
+         lambda: _lib.load().xvit_cls_softmax_fwd(_ptr(s), ld, _ptr(e), 16, _ptr(rz), B, H, N, scale, _ptr(em), float(dropout[0]) if drop else 0.0,
+                                                  int(dropout[1]) if drop else 0, _stream()), "xvit_cls_softmax_fwd")
+    return (e, rz, em) if drop else (e, rz)
 
 
-def cls_softmax_bwd(e, rz, dp, H, scale):
-    """-> (coef fp32 [B, N, 2H] = (ds | p), ds bf16 [B, N, 16]); p = e rz, ds = scale p (dp - sum_n p dp)."""
+def head_bias_grad(x, w, H):
+    """out[j] = sum_b x[b, j] w[b, j // 64] (xvit_head_bias_grad): bv's gradient when the weights in front of it are w, not one."""
+    B, d = x.shape
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and w.shape == (B, H) and x.stride(1) == 1 and w.stride(1) == 1
+    out = torch.empty(d, dtype=torch.float32, device=x.device)
+    _run("head_linear", 2.0 * B * d, "flop", lambda: _lib.load().xvit_head_bias_grad(_ptr(x), x.stride(0), _ptr(w), w.stride(0), _ptr(out), B, H, d, _stream()), "xvit_head_bias_grad")
+    return out
+
+
+def cls_softmax_bwd(e, rz, dp, H, scale, dropout=None):
+    """-> (coef fp32 [B, N, 2H] = (ds | p'), ds bf16 [B, N, 16]); p = e rz, ds = scale p (dp~ - sum_n p dp~); with dropout = (p, seed) dp~ = m dp / (1 - p) and
+    p' = m p / (1 - p) (the forward's mask, regenerated), else dp~ = dp, p' = p.  rz: fp32 [B, H] (row 0 of the forward's stat block under dropout)."""
     B, N, _ = e.shape
+    drop = dropout is not None and dropout[0] > 0.0
+    assert rz.shape == (B, H) and rz.is_contiguous()
     assert e.dtype == torch.bfloat16 and e.is_contiguous() and dp.dtype == torch.float32 and dp.is_contiguous() and dp.shape == (B, N, 16)
     coef = torch.empty(B, N, 2 * H, dtype=torch.float32, device=e.device)
     dsb = torch.empty(B, N, 16, dtype=torch.bfloat16, device=e.device)
     _run("cls_softmax", B * N * (16 * 8.0 + 2 * H * 4.0), "byte",
-         lambda: _lib.load().xvit_cls_softmax_bwd(_ptr(e), 16, _ptr(rz), _ptr(dp), 16, _ptr(coef), _ptr(dsb), 16, B, H, N, scale, _stream()), "xvit_cls_softmax_bwd")
+         lambda: _lib.load().xvit_cls_softmax_bwd(_ptr(e), 16, _ptr(rz), _ptr(dp), 16, _ptr(coef), _ptr(dsb), 16, B, H, N, scale, float(dropout[0]) if drop else 0.0,
+                                                  int(dropout[1]) if drop else 0, _stream()), "xvit_cls_softmax_bwd")
     return coef, dsb
 
 

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define XVIT_VERSION 301 /* 0.3.1: xvit_set_dropout_epoch; 0.3.0: workspaces in xvit_attn_fwd/bwd (CLS peel), xvit_linear_f32_batched; 0.2.0: ld_alt in xvit_layernorm_fwd/bwd, dropout in xvit_attn_*, xvit_patch_embed_*, xvit_attn_fwd_fp8, xvit_linear_f32, workspaces */
+#define XVIT_VERSION 302 /* 0.3.2: probability dropout in the low-rank fusion (xvit_cls_softmax_*, xvit_head_cols bias_scale, xvit_head_bias_grad), xvit_xattn_kv_wgrad removed; 0.3.1: xvit_set_dropout_epoch; 0.3.0: workspaces in xvit_attn_fwd/bwd (CLS peel), xvit_linear_f32_batched; 0.2.0: ld_alt in xvit_layernorm_fwd/bwd, dropout in xvit_attn_*, xvit_patch_embed_*, xvit_attn_fwd_fp8, xvit_linear_f32, workspaces */
 
 enum { XVIT_OK = 0, XVIT_ERR_ARG = -1, XVIT_ERR_UNSUPPORTED = -2 };
 enum { XVIT_BF16 = 0, XVIT_F32 = 1 };
@@ -185,16 +185,11 @@ int xvit_cls_xattn_bwd(const void* q, int64_t ldq, const void* k, const void* v,
                        const void* d_o, int64_t lddo, float* dq, int64_t lddq, void* dk, void* dv, float* coef, int B, int H, int N, int dh,
                        float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
 /* dk / dv (bf16, laid out like k / v; both or neither) and / or coef (fp32 [B, N, 2 H]).  dK and dV of one (b, head) are rank one:
- * dk[n] = coef[b][n][head] * q_head (the softmax scale included), dv[n] = coef[b][n][H + head] * dO_head.  With coef the gradient
- * of the K/V projection (model_cross.py:92-93: wk, wv over all N tokens) is taken in that low-rank form, without the [B N, 2 d] tensor:
- *   xvit_xattn_kv_dgrad: dhn[b, n, :] (bf16) = dk[b, n, :] Wk + dv[b, n, :] Wv = sum_j coef[b, n, j] R[j, b, :], with R (fp32 [2 H, B, d])
- *     R[h, b, :] = q[b, h, :] Wk[64 h .. 64 h + 63, :], R[H + h, b, :] = dO[b, h, :] Wv[64 h .., :] supplied by the caller (one batched product);
- *   xvit_xattn_kv_wgrad: part[slice][j][b][:] (fp32) = sum over the slice's rows n of coef[b, n, j] hn[b, n, :]; summed over the slices
- *     (fixed order) this is T[j, b, :], and dWk[64 h + e, :] = sum_b q[b, h, e] T[h, b, :], dWv likewise with dO and T[H + h, b, :].
- *   xvit_xattn_kv_wgrad_partials: number of floats `part` must hold.  d = 64 H, 2 H <= 32. */
+ * dk[n] = coef[b][n][head] * q_head (the softmax scale included), dv[n] = coef[b][n][H + head] * dO_head.
+ *   xvit_xattn_kv_dgrad (the low-rank fusion's token gradient): dhn[b, n, :] (bf16) = dk[b, n, :] Wk + dv[b, n, :] Wv
+ *     = sum_j coef[b, n, j] R[j, b, :], with R (fp32 [2 H, B, d]): R[h, b, :] = q[b, h, :] Wk[64 h .. 64 h + 63, :],
+ *     R[H + h, b, :] = dO[b, h, :] Wv[64 h .., :] (xvit_head_rows).  d = 64 H, 2 H <= 32. */
 int xvit_xattn_kv_dgrad(const float* coef, const float* R, void* dhn_bf16, int64_t lddh, int B, int H, int N, int d, xvit_stream_t stream);
-int64_t xvit_xattn_kv_wgrad_partials(int B, int H, int N, int d);
-int xvit_xattn_kv_wgrad(const float* coef, const void* hn_bf16, int64_t ldh, float* part, int B, int H, int N, int d, xvit_stream_t stream);
 
 /* The fusion's key / value path in its low-rank form (model_cross.py:88-99): with one query row per (sample, head),
  *   scores[b, n, h] = hn[b, n, :] . U[b, h, :] (+ a constant over n),  U[b, h, :] = q[b, h, :] Wk[64 h .. 64 h + 63, :]          (xvit_head_rows)
@@ -205,19 +200,28 @@ int xvit_xattn_kv_wgrad(const float* coef, const void* hn_bf16, int64_t ldh, flo
  * xvit_xattn_kv_dgrad) and bf16 ds, T = sum_n ds hn (xvit_gemm), dq = Wk_h T (xvit_head_cols), dWk_h = q_h^T T, dWv_h = dO_h^T (rz S)
  * (xvit_head_wgrad).  All per-head products are fp32 on the f32-input MFMA against the fp32 master weights; d = 64 H, H <= 16.
  *   xvit_head_rows : out[b, h, c] (fp32, element strides out_sb / out_sh; optional bf16 copy with its own strides) = sum_e x[b, 64 h + e] W[64 h + e, c]
- *   xvit_head_cols : out[b, 64 h + e] (fp32, row stride ldo; optional bf16 copy) = row_scale[b, h] * sum_c t[b, h, c] W[64 h + e, c] + bias[64 h + e]
- *   xvit_head_wgrad: dW[64 h + e, c] = sum_b x[b, 64 h + e] row_scale[b, h] t[b, h, c]                                                   */
+ *   xvit_head_cols : out[b, 64 h + e] (fp32, row stride ldo; optional bf16 copy) = row_scale[b, h] * sum_c t[b, h, c] W[64 h + e, c]
+ *                    + bias_scale[b, h] * bias[64 h + e]   (row_scale, bias, bias_scale optional: 1, 0, 1)
+ *   xvit_head_wgrad: dW[64 h + e, c] = sum_b x[b, 64 h + e] row_scale[b, h] t[b, h, c]
+ *   xvit_head_bias_grad: out[j] = sum_b x[b, j] w[b, j / 64] (the gradient of bv under dropout; samples summed in order)
+ * Dropout on the probabilities (attn_drop, model_cross.py:97; the reference trains with 0.1 .. 0.25): p'[n] = m[n] p[n] / (1 - rate) with
+ * the mask xvit_cls_xattn_fwd uses (xvit_dropout on a contiguous [B, H, N] tensor).  xvit_cls_softmax_fwd then also writes the KEPT weights
+ * e_masked (the operand of the row-sum GEMM: S = sum_n e_masked hn) and rz becomes a [3][B][H] block: rz, rz / (1 - rate) (the row scale
+ * of xvit_head_cols and of dWv) and rz / (1 - rate) * sum_n e_masked (bias_scale: the weight in front of bv, which no longer is one);
+ * xvit_cls_softmax_bwd regenerates the mask: dp~ = m dp / (1 - rate) replaces dp and the second half of coef is p'.                    */
 int xvit_head_rows(const float* x, int64_t ldx, const float* W, int64_t ldw, float* out, int64_t out_sb, int64_t out_sh, void* out_bf16, int64_t ob_sb,
                    int64_t ob_sh, int ob_heads, int B, int H, int d, xvit_stream_t stream);   /* head rows H .. ob_heads - 1 of the bf16 copy are zeroed */
 int xvit_head_cols(const float* t, int64_t t_sb, int64_t t_sh, const float* W, int64_t ldw, const float* row_scale, int64_t rs_ld, const float* bias,
-                   float* out, int64_t ldo, void* out_bf16, int64_t ldob, int B, int H, int d, xvit_stream_t stream);
+                   const float* bias_scale, int64_t bsc_ld, float* out, int64_t ldo, void* out_bf16, int64_t ldob, int B, int H, int d, xvit_stream_t stream);
+int xvit_head_bias_grad(const float* x, int64_t ldx, const float* w, int64_t ldw, float* out, int B, int H, int d, xvit_stream_t stream);
 int xvit_head_wgrad(const float* x, int64_t ldx, const float* t, int64_t t_sb, int64_t t_sh, const float* row_scale, int64_t rs_ld, float* dW, int64_t lddw,
                     int B, int H, int d, xvit_stream_t stream);
-/* s [B, N, lds] fp32 -> e [B, N, lde] bf16 (columns >= H zeroed; lde <= 16), rz [B, H] */
-int xvit_cls_softmax_fwd(const float* s, int64_t lds, void* e_bf16, int64_t lde, float* rz, int B, int H, int N, float scale, xvit_stream_t stream);
-/* p = e rz; ds = scale p (dp - sum_n p dp) -> coef [B, N, 2 H] fp32 = (ds | p), ds_bf16 [B, N, ldb] (columns >= H zeroed) */
+/* s [B, N, lds] fp32 -> e [B, N, lde] bf16 (columns >= H zeroed; lde <= 16), rz [B, H]; dropout_p > 0: also e_masked (like e) and rz is [3][B][H] */
+int xvit_cls_softmax_fwd(const float* s, int64_t lds, void* e_bf16, int64_t lde, float* rz, int B, int H, int N, float scale, void* e_masked_bf16,
+                         float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
+/* p = e rz; ds = scale p (dp~ - sum_n p dp~) -> coef [B, N, 2 H] fp32 = (ds | p'), ds_bf16 [B, N, ldb] (columns >= H zeroed) */
 int xvit_cls_softmax_bwd(const void* e_bf16, int64_t lde, const float* rz, const float* dp, int64_t ldp, float* coef, void* ds_bf16, int64_t ldb, int B, int H,
-                         int N, float scale, xvit_stream_t stream);
+                         int N, float scale, float dropout_p, uint64_t dropout_seed, xvit_stream_t stream);
 
 /* MX-fp8 forward attention (BASELINE.json configs[4] "fp8 MFMA QK^T/AV path"; reference ops model_cross.py:55-59):
  * same arguments and outputs as xvit_attn_fwd without dropout, but q, k, v are first quantised to OCP e4m3 with one e8m0

@@ -20,3 +20,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _fusion_form_of_the_bench_path(request, monkeypatch):
+    """GPU tests run at small batches, where the default ("auto") would pick the fusion's literal order (bound by the host there); the path
+    the bench runs is the low-rank form, so that is what the parity tests exercise unless a test selects a form itself."""
+    if request.node.get_closest_marker("gpu") is not None:
+        import xvit.functional as XF
+        monkeypatch.setattr(XF, "XATTN_FORM", "lowrank")
+    yield

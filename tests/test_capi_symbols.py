@@ -68,13 +68,18 @@ def test_head_linear_argument_errors_do_not_launch():
     assert lib.xvit_head_rows(None, 768, P, 768, P, 768, 64, None, 0, 0, 0, 8, 12, 768, None) < 0 and b"null" in lib.xvit_last_error_string()
     assert lib.xvit_head_rows(P, 768, P, 768, P, 768, 64, None, 0, 0, 0, 8, 12, 700, None) < 0 and b"64 H" in lib.xvit_last_error_string()
     assert lib.xvit_head_rows(P, 766, P, 768, P, 768, 64, None, 0, 0, 0, 8, 12, 768, None) < 0            # ldx not a multiple of 4 floats / < d
-    assert lib.xvit_head_cols(P, 768, 64, P, 766, None, 0, None, P, 768, None, 0, 8, 12, 768, None) < 0   # ldw not a multiple of 4 floats
-    assert lib.xvit_head_cols(P + 4, 768, 64, P, 768, None, 0, None, P, 768, None, 0, 8, 12, 768, None) < 0   # t not 16-byte aligned
+    assert lib.xvit_head_cols(P, 768, 64, P, 766, None, 0, None, None, 0, P, 768, None, 0, 8, 12, 768, None) < 0   # ldw not a multiple of 4 floats
+    assert lib.xvit_head_cols(P + 4, 768, 64, P, 768, None, 0, None, None, 0, P, 768, None, 0, 8, 12, 768, None) < 0   # t not 16-byte aligned
+    assert lib.xvit_head_bias_grad(P, 512, P, 12, P, 8, 12, 768, None) < 0                                # ldx < d
+    assert lib.xvit_head_bias_grad(P, 768, P, 8, P, 8, 12, 768, None) < 0                                 # ldw < H
     assert lib.xvit_head_wgrad(P, 512, P, 768, 64, None, 0, P, 768, 8, 12, 768, None) < 0                 # ldx < d
-    assert lib.xvit_cls_softmax_fwd(P, 32, P, 16, P, 8, 32, 513, 0.125, None) < 0 and b"H <= 16" in lib.xvit_last_error_string()
-    assert lib.xvit_cls_softmax_fwd(P, 12, P, 8, P, 8, 12, 513, 0.125, None) < 0                          # lde < H
-    assert lib.xvit_cls_softmax_bwd(P, 16, P, P, 12, P, P, 32, 8, 12, 513, 0.125, None) < 0               # ldb > 16
-    assert lib.xvit_cls_softmax_bwd(P, 16, None, P, 12, P, P, 16, 8, 12, 513, 0.125, None) < 0            # null rz
+    assert lib.xvit_cls_softmax_fwd(P, 32, P, 16, P, 8, 32, 513, 0.125, None, 0.0, 0, None) < 0 and b"H <= 16" in lib.xvit_last_error_string()
+    assert lib.xvit_cls_softmax_fwd(P, 12, P, 8, P, 8, 12, 513, 0.125, None, 0.0, 0, None) < 0            # lde < H
+    assert lib.xvit_cls_softmax_fwd(P, 16, P, 16, P, 8, 12, 513, 0.125, None, 0.25, 1, None) < 0 and b"e_masked" in lib.xvit_last_error_string()
+    assert lib.xvit_cls_softmax_bwd(P, 16, P, P, 12, P, P, 32, 8, 12, 513, 0.125, 0.0, 0, None) < 0       # ldb > 16
+    assert lib.xvit_cls_softmax_bwd(P, 16, None, P, 12, P, P, 16, 8, 12, 513, 0.125, 0.0, 0, None) < 0    # null rz
+    assert lib.xvit_cls_softmax_bwd(P, 16, P, P, 16, P, P, 16, 8, 12, 513, 0.125, 1.0, 0, None) < 0       # dropout_p out of range
+    assert lib.xvit_set_dropout_epoch(P + 4) < 0 and lib.xvit_set_dropout_epoch(None) == 0                 # 8-byte aligned counter, NULL = off
 
 
 def test_modules_have_reference_state_dict_keys():

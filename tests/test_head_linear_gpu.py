@@ -80,3 +80,44 @@ def test_low_rank_attention_equals_the_literal_order(B, H, N):
     p = torch.softmax(torch.einsum("bhe,bnhe->bhn", q.double().view(B, H, 64), k) * scale, dim=-1)
     ref = torch.einsum("bhn,bnhe->bhe", p, v).reshape(B, d)
     assert rel(o, ref) < 3e-3, rel(o, ref)       # bf16 U and bf16 softmax weights; everything else fp32
+
+
+@pytest.mark.parametrize("B,H,N", [(5, 12, 513), (2, 3, 17), (3, 16, 130)])
+def test_cls_softmax_with_probability_dropout(B, H, N):
+    """attn_drop on the probabilities (model_cross.py:97) inside the low-rank form: the kept weights, the three stat rows, and the backward
+    with the regenerated mask — against fp64 with the very mask xvit_dropout draws on a contiguous [B, H, N] tensor (the one
+    xvit_cls_xattn_fwd applies in the literal order)."""
+    from xvit import ops
+    pr, seed, scale = 0.25, 20240607, 0.125
+    s = torch.zeros(B, N, 16)
+    s[:, :, :H] = randn(B, N, H, seed=1) * 4
+    e0, rz0 = ops.cls_softmax_fwd(s.to(dev()), H, scale)
+    e, stat, ek = ops.cls_softmax_fwd(s.to(dev()), H, scale, dropout=(pr, seed))
+    mask = (ops.dropout(torch.ones(B, H, N, device=dev()), pr, seed) != 0).permute(0, 2, 1)              # [B, N, H] keep flags
+    assert 0.6 < float(mask.float().mean()) < 0.9
+    assert torch.equal(e, e0) and torch.equal(stat[0], rz0)                                               # the undropped softmax is untouched
+    assert torch.equal(ek[:, :, :H], torch.where(mask, e[:, :, :H], torch.zeros_like(e[:, :, :H])))
+    assert H == 16 or float(ek[:, :, H:].float().abs().max()) == 0.0
+    inv = 1.0 / (1.0 - pr)
+    assert rel(stat[1], rz0 * inv) < 1e-6
+    assert rel(stat[2], rz0 * inv * ek[:, :, :H].float().sum(dim=1)) < 1e-5
+    # head_cols with the bias weighted by stat[2]; head_bias_grad is its transpose
+    d = 64 * H
+    t, W, bias = randn(B, 16, d, seed=3), randn(d, d, seed=2, scale=d ** -0.5), randn(d, seed=5)
+    out, _ = ops.head_cols(t.to(dev()), W.to(dev()), H, row_scale=stat[1], bias=bias.to(dev()), bias_scale=stat[2])
+    ref = (torch.einsum("bhc,hec->bhe", t[:, :H].double(), W.double().view(H, 64, d)) * stat[1].double().cpu()[:, :, None]
+           + bias.double().view(1, H, 64) * stat[2].double().cpu()[:, :, None]).reshape(B, d)
+    assert rel(out, ref) < 2e-6
+    x = randn(B, d, seed=7)
+    gb = ops.head_bias_grad(x.to(dev()), stat[2], H)
+    assert rel(gb, (x.double().view(B, H, 64) * stat[2].double().cpu()[:, :, None]).sum(0).reshape(d)) < 2e-6
+    # backward: dp is the gradient of the DROPPED probabilities
+    dp = torch.zeros(B, N, 16)
+    dp[:, :, :H] = randn(B, N, H, seed=2)
+    coef, dsb = ops.cls_softmax_bwd(e, stat[0], dp.to(dev()), H, scale, dropout=(pr, seed))
+    p = e[:, :, :H].double().cpu() * rz0.double().cpu()[:, None, :]
+    m = mask.double().cpu() * inv
+    dpt = m * dp[:, :, :H].double()
+    ds = scale * p * (dpt - (p * dpt).sum(dim=1, keepdim=True))
+    assert rel(coef[:, :, :H], ds) < 1e-5 and rel(coef[:, :, H:], p * m) < 1e-6
+    assert torch.equal(dsb[:, :, :H], coef[:, :, :H].to(torch.bfloat16))
