@@ -16,8 +16,15 @@ NT, NN, TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
 
+# Host cost matters at the reference's batch (8 volume pairs: ~500 launches per step against 4.4 ms of GPU work): the current device
+# and its current stream are read through torch's C entry points (what torch.cuda.current_device / current_stream wrap, without the
+# lazy-init checks and the Stream object per call: 9 us -> 0.3 us).
+_cur_dev = torch._C._cuda_getDevice
+_raw_stream = torch._C._cuda_getCurrentRawStream
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(_cur_dev())
 
 
 # Optional live per-kernel timing (bench.py): when PROFILE is a list, every wrapper brackets its
@@ -79,7 +86,7 @@ def _ptr(t) -> int | None:
         return None
     if not t.is_cuda:
         raise RuntimeError("xvit: tensor is not on the GPU; the HIP path has no CPU fallback")
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != _cur_dev():
         # launches go to the CURRENT device's current stream (_stream()): a tensor of another GPU would be written by a
         # kernel on the wrong device, unordered with torch's own work on the tensor's device
         raise RuntimeError(f"xvit: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
