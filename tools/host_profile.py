@@ -51,3 +51,35 @@ pr.disable()
 torch.cuda.synchronize()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
+
+# ---- the backward runs on the autograd engine's thread, which cProfile above does not see: wall time inside every Function.backward
+# (launches are asynchronous, so this is host time) and a cProfile of one block's backward called directly
+import collections  # noqa: E402
+import xvit.functional as XF  # noqa: E402
+from xvit import cross_vit as CV  # noqa: E402
+
+acc = collections.Counter()
+cnt = collections.Counter()
+
+
+def timed(cls):
+    orig = cls.backward
+
+    def wrapper(ctx, *a):
+        t = time.perf_counter()
+        out = orig(ctx, *a)
+        acc[cls.__name__] += time.perf_counter() - t
+        cnt[cls.__name__] += 1
+        return out
+    cls.backward = staticmethod(wrapper)
+
+
+for c in (XF.SelfAttentionBlockFn, XF.CrossFusionFn, XF.PatchEmbedFn, XF.HeadFn, XF.MeanCrossEntropyFn, CV._FanOut):
+    timed(c)
+for _ in range(steps):
+    step()
+torch.cuda.synchronize()
+print("host time inside Function.backward, ms per step:")
+for k, v in acc.most_common():
+    print(f"  {k:28s} {v / steps * 1e3:7.3f} ms  ({cnt[k] // steps} calls, {v / cnt[k] * 1e6:6.1f} us each)")
+print(f"  total {sum(acc.values()) / steps * 1e3:.3f} ms")
