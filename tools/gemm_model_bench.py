@@ -3,7 +3,7 @@
 wgrad), timed per tile kernel, variants interleaved in one process (HIP events, random bf16 operands).  Prints the time,
 the algorithmic TFLOP/s and the algorithmic HBM GB/s (compulsory operand + epilogue bytes) of every case.
 
-    python tools/gemm_model_bench.py [batch] [variant ...]     variants: auto narrow tile128 auxz g1..g12
+    python tools/gemm_model_bench.py [batch] [variant ...]     variants: auto narrow tile128 tile256 auxz g1..g12
 """
 import os
 import sys
@@ -77,7 +77,7 @@ def cases():
     return out
 
 
-VARIANTS = {"auto": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", 0)), "auxz": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", 0)), "narrow": (("gemm_tile", 0), ("gemm_epilogue", 1)), "tile128": (("gemm_tile", 1), ("gemm_epilogue", 0)),
+VARIANTS = {"auto": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", 0)), "auxz": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", 0)), "narrow": (("gemm_tile", 0), ("gemm_epilogue", 1)), "tile128": (("gemm_tile", 1), ("gemm_epilogue", 0)), "tile256": (("gemm_tile", 2), ("gemm_epilogue", 0)),
             **{f"g{n}": (("gemm_tile", 0), ("gemm_epilogue", 0), ("gemm_group", n)) for n in (1, 2, 3, 4, 6, 12)}}
 
 
