@@ -85,6 +85,18 @@ __global__ void cast_kernel(const float* __restrict__ src, bf16* __restrict__ ds
   if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[(nv << 3) + threadIdx.x] = f2bf(src[(nv << 3) + threadIdx.x]);
 }
 
+// out = a + b (fp32) with a bf16 copy of the sum: the fan-out sum of two gradient tensors (cross_vit._FanOut) handed on in both dtypes,
+// one pass instead of an add and a cast (n % 8 == 0: rows of d % 8 == 0 floats)
+__global__ void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, bf16* __restrict__ outb, int64_t n) {
+  const int64_t nv = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 s0 = ((const f32x4*)a)[2 * i] + ((const f32x4*)b)[2 * i], s1 = ((const f32x4*)a)[2 * i + 1] + ((const f32x4*)b)[2 * i + 1];
+    ((f32x4*)out)[2 * i] = s0;
+    ((f32x4*)out)[2 * i + 1] = s1;
+    ((bf16x8*)outb)[i] = bf16x8{f2bf(s0[0]), f2bf(s0[1]), f2bf(s0[2]), f2bf(s0[3]), f2bf(s1[0]), f2bf(s1[1]), f2bf(s1[2]), f2bf(s1[3])};
+  }
+}
+
 __global__ void zero_f32_kernel(float* __restrict__ p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0.f;
@@ -288,6 +300,14 @@ extern "C" int xvit_cast_f32_bf16(const float* src, void* dst, int64_t n, xvit_s
   XVIT_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0, "xvit_cast_f32_bf16: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(cast_kernel, dim3(grid_for(n / 8 + 1, 256)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n);
   return check_launch("xvit_cast_f32_bf16");
+}
+
+extern "C" int xvit_add_cast_f32_bf16(const float* a, const float* b, float* out, void* out_bf16, int64_t n, xvit_stream_t stream) {
+  XVIT_REQUIRE(a && b && out && out_bf16 && n > 0 && n % 8 == 0, "xvit_add_cast_f32_bf16: bad arguments (n must be a positive multiple of 8)");
+  XVIT_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(out_bf16)) & 15) == 0,
+               "xvit_add_cast_f32_bf16: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (bf16*)out_bf16, n);
+  return check_launch("xvit_add_cast_f32_bf16");
 }
 
 static int colsum_rows_per_block(int rows, int n) {

@@ -95,6 +95,7 @@ class SelfAttentionBlock(nn.Module):
         super().__init__()
         self.attn = PreNorm(config, Attention(config, dim_head=(config.hidden_dim // config.num_heads)))
         self.ffn = PreNorm(config, FeedForward(config))
+        self.feeds_a_block = False     # set by MultiScaleBlock for the blocks behind another one in a branch (XF.attach_b16)
 
     def forward(self, x):
         a, f = self.attn, self.ffn
@@ -104,7 +105,7 @@ class SelfAttentionBlock(nn.Module):
         return XF.SelfAttentionBlockFn.apply(
             x, a.norm.weight, a.norm.bias, a.fn.to_qkv.weight, a.fn.to_out[0].weight, a.fn.to_out[0].bias,
             f.norm.weight, f.norm.bias, f.fn.net[0].weight, f.fn.net[0].bias, f.fn.net[3].weight, f.fn.net[3].bias,
-            a.fn.heads, a.norm.eps, _p(self, f.fn.net[2]))
+            a.fn.heads, a.norm.eps, _p(self, f.fn.net[2]), self.feeds_a_block and not self._forward_hooks and not self._forward_pre_hooks)
 
 
 class CrossAttention(nn.Module):
@@ -156,9 +157,11 @@ class _FanOut(torch.autograd.Function):
     node — the pattern the branch fork already uses."""
 
     @staticmethod
-    def forward(ctx, x, n, cls_first=False):
-        """cls_first: reader 0 (the modality's own fusion in a cls-only block, which uses nothing but the CLS rows) gets x[:, :1]."""
+    def forward(ctx, x, n, cls_first=False, want_b16=False):
+        """cls_first: reader 0 (the modality's own fusion in a cls-only block, which uses nothing but the CLS rows) gets x[:, :1].
+        want_b16: x was produced by a SelfAttentionBlock: hand the summed gradient on in bf16 as well (XF.attach_b16)."""
         ctx.cls_first = cls_first
+        ctx.want_b16 = bool(want_b16) and XF.B16_HANDOFF
         outs = [x.view_as(x) for _ in range(n)]
         if cls_first:
             outs[0] = x[:, :1]
@@ -170,15 +173,25 @@ class _FanOut(torch.autograd.Function):
         gs = [g for g in (gs[1:] if ctx.cls_first else gs) if g is not None]
         if not gs:
             return None, None, None
-        total = gs[0]
-        for g in gs[1:]:
-            total = total + g
+        total, tb = gs[0], None
+        if len(gs) == 2 and ctx.want_b16 and gs[0].is_cuda and gs[0].dtype == torch.float32 and gs[1].dtype == torch.float32 \
+                and gs[0].shape == gs[1].shape and gs[0].is_contiguous() and gs[1].is_contiguous() and gs[0].numel() % 8 == 0:
+            total, tb = XF.ops.add_cast(gs[0], gs[1])      # the sum and its bf16 copy in one pass (the reader is a block's backward)
+        else:
+            for g in gs[1:]:
+                total = total + g
+            if len(gs) == 1 and ctx.want_b16:
+                tb = XF.b16_of(total, (total.shape[0] * total.shape[1], total.shape[2])) if total.dim() == 3 else None   # a fusion's dcat came in both dtypes
         if narrow is not None:
             if len(gs) == 1 and not total.is_contiguous():
-                total = total.contiguous()
+                total, tb = total.contiguous(), None
             total[:, :1] += narrow                          # in place: `total` is a fusion's freshly written dcat (this node is its only reader) or the sum above
+            if tb is not None:
+                tb.view(total.shape)[:, :1] = total[:, :1]  # B rows of the bf16 copy follow
         XF.keep(total, *gs, narrow)
-        return total, None, None
+        if tb is not None:
+            total = XF.attach_b16(total, tb)
+        return total, None, None, None
 
 
 _SIDE_STREAMS: dict = {}
@@ -271,6 +284,12 @@ class MultiScaleBlock(nn.Module):
         exclusive (ModelCross only): every output has exactly one consumer, whose backward returns a fresh gradient tensor —
         together with "the branch output was produced here and no forward hook saw it" that lets a fusion splice its CLS
         rows into the branch output in place (XF.CrossFusionFn); a direct caller gets the reference's copying cat."""
+        for seq in self.blocks:          # a block whose input is another block's output returns its input gradient in bf16 too
+            prev = None
+            for blk in seq:
+                if isinstance(blk, SelfAttentionBlock):
+                    blk.feeds_a_block = isinstance(prev, SelfAttentionBlock) and not prev._forward_hooks
+                prev = blk
         attn = self._branches(x)
         # every reader of a branch output (its own fusion, other fusions that take its patch tokens, the pass-through) gets
         # its own alias, so the gradients are summed by _FanOut instead of across streams inside the engine
@@ -284,7 +303,9 @@ class MultiScaleBlock(nn.Module):
             fan = len(readers[i]) > 1 and a.is_cuda and a.requires_grad and os.environ.get("XVIT_FANOUT", "1") == "1"
             # cls-only block: the own fusion reads nothing but the CLS rows of its modality: hand it those alone
             cls_first = fan and cls_only and readers[i][0] == ("own", i) and self.attn_order.get(str(i)) != str(i) and os.environ.get("XVIT_CLS_NARROW", "1") == "1"
-            outs_i = _FanOut.apply(a, len(readers[i]), cls_first) if fan else [a] * len(readers[i])
+            last_blk = self.blocks[i][-1] if len(self.blocks[i]) > 0 else None
+            from_block = isinstance(last_blk, SelfAttentionBlock) and not last_blk._forward_hooks and not self.blocks[i]._forward_hooks
+            outs_i = _FanOut.apply(a, len(readers[i]), cls_first, from_block) if fan else [a] * len(readers[i])
             for r, t in zip(readers[i], outs_i):
                 alias[(i,) + r] = t
         thunks = []

@@ -185,6 +185,33 @@ def release_capture_keep():
 
 
 # ------------------------------------------------------------------------------------------
+# Gradients handed from one backward node to the next in BOTH dtypes.  A block's backward starts by casting its incoming fp32
+# gradient to bf16 (the operand of its first GEMMs): a pass over 297 MB at configs[1].  The node that produced the gradient — the next
+# block's LayerNorm backward, a fusion's, or the fan-out sum — can write the bf16 copy in the pass it makes anyway.  The copy rides
+# on the gradient tensor as an attribute (the engine hands the very tensor object to the next node when that node is its only
+# reader; any accumulation or hook in between yields a new tensor without it and the consumer casts as before).
+# ------------------------------------------------------------------------------------------
+
+B16_HANDOFF = os.environ.get("XVIT_B16_HANDOFF", "1") == "1"
+
+
+def attach_b16(t, tb):
+    """`tb`: bf16 copy of the gradient `t` about to be returned to autograd."""
+    if tb is not None and B16_HANDOFF:
+        t._xvit_b16 = tb
+        keep(tb)
+    return t
+
+
+def b16_of(t, shape):
+    """The bf16 copy that came with gradient `t` (same device, the expected 2-D shape), or None."""
+    tb = getattr(t, "_xvit_b16", None) if B16_HANDOFF else None
+    if tb is not None and tb.dtype == torch.bfloat16 and tb.device == t.device and tb.numel() == shape[0] * shape[1] and tb.is_contiguous():
+        return tb.view(shape)
+    return None
+
+
+# ------------------------------------------------------------------------------------------
 # dropout: counter-based masks.  A site's mask is a pure function of (seed, element index), so the
 # backward pass regenerates it instead of storing it; seeds derive from torch's global seed and
 # a call counter (reproducible under torch.manual_seed, different at every call).
@@ -395,15 +422,17 @@ def block_forward(x, B, N, H, eps, scale, ln1w, ln1b, wqkv_s, bqkv, wo_s, bo, ln
     return x2, (x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a)
 
 
-def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w, w1_s, w2_s, p_out=0.0, p_ffn=0.0, seeds=(0, 0, 0), p_attn=0.0, seed_attn=0):
+def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w, w1_s, w2_s, p_out=0.0, p_ffn=0.0, seeds=(0, 0, 0), p_attn=0.0, seed_attn=0,
+                   dy_b16=None, want_dx_b16=False):
     """dy fp32 [B*N, d] -> (dx, grads dict).  Bias gradients cost no extra pass: b2 and bo fall out of the
-    LN2 backward (column sums of its dres and dx), b1 out of the GELU' dgrad epilogue."""
+    LN2 backward (column sums of its dres and dx), b1 out of the GELU' dgrad epilogue.  dy_b16: the bf16 copy of dy when the producer
+    supplied one (b16_of); want_dx_b16: also return dx in bf16 (g["dx_b16"]) for the block in front."""
     x, mu1, rs1, h1, qkv, o, lse, x1, mu2, rs2, h2, z, a = saved
     d, f = x.shape[1], z.shape[1]
     zero = _zeros(6 * d + f, x)                               # every atomically-accumulated vector of this block
     g = dict(zip(("ln2w", "ln2b", "bo", "b2", "ln1w", "ln1b"), zero[:6 * d].split(d)))
     g["b1"] = zero[6 * d:]
-    dyb = _masked(ops.cast_bf16(dy), p_ffn, seeds[2])        # d(FFN out) = dy * mask
+    dyb = _masked(dy_b16 if dy_b16 is not None else ops.cast_bf16(dy), p_ffn, seeds[2])        # d(FFN out) = dy * mask
     # FFN
     dz = _dgrad(dyb, w2_s, act=ops.ACT_DGELU, aux=z, colsum=g["b1"], dropout=_dp(p_ffn, seeds[1]), aux_mode=AUX_MODE)
     g["w2"] = _wgrad(dyb, a, w2_s)
@@ -425,7 +454,7 @@ def block_backward(dy, saved, B, N, H, scale, ln1w, wqkv_s, has_bqkv, wo_s, ln2w
     g["wqkv"] = _wgrad(dqkv, h1, wqkv_s)
     if has_bqkv:
         g["bqkv"] = ops.colsum(dqkv)
-    dx, _ = ops.layernorm_bwd(dh1, x, mu1, rs1, ln1w, g["ln1w"], g["ln1b"], dres=dx1)
+    dx, g["dx_b16"] = ops.layernorm_bwd(dh1, x, mu1, rs1, ln1w, g["ln1w"], g["ln1b"], dres=dx1, want_bf16=want_dx_b16)
     _join_wgrads(x.device)
     return dx, g
 
@@ -434,9 +463,12 @@ class SelfAttentionBlockFn(Function):
     """model_cross.SelfAttentionBlock: fused-qkv (no bias), eps 1e-5, scale dh**-0.5."""
 
     @staticmethod
-    def forward(ctx, x, ln1w, ln1b, wqkv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps, p=0.0):
+    def forward(ctx, x, ln1w, ln1b, wqkv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, H, eps, p=0.0, feeds_a_block=False):
+        """feeds_a_block: the gradient this node returns for x goes to another SelfAttentionBlockFn (the block in front of it in a
+        branch): hand it on in bf16 as well (attach_b16)."""
         B, N, d = x.shape
         scale = (d // H) ** -0.5
+        ctx.feeds_a_block = bool(feeds_a_block)
         sh = (SHADOWS.get(wqkv), SHADOWS.get(wo), SHADOWS.get(w1), SHADOWS.get(w2))
         seeds = drop_seeds(3) if p > 0.0 else (0, 0, 0)
         x2, saved = block_forward(_f32c(x).reshape(B * N, d), B, N, H, eps, scale, ln1w, ln1b, sh[0], None, sh[1], bo, ln2w, ln2b, sh[2], b1, sh[3], b2,
@@ -450,9 +482,12 @@ class SelfAttentionBlockFn(Function):
     def backward(ctx, dy):
         B, N, H, scale, xdt = ctx.meta
         ln1w, ln2w, wqkv_s, wo_s, w1_s, w2_s, *saved = ctx.saved_tensors
-        dx, g = block_backward(_f32c(dy).reshape(B * N, -1), saved, B, N, H, scale, ln1w, wqkv_s, False, wo_s, ln2w, w1_s, w2_s, *ctx.drop)
+        d = ln1w.shape[0]
+        dx, g = block_backward(_f32c(dy).reshape(B * N, -1), saved, B, N, H, scale, ln1w, wqkv_s, False, wo_s, ln2w, w1_s, w2_s, *ctx.drop,
+                               dy_b16=b16_of(dy, (B * N, d)), want_dx_b16=ctx.feeds_a_block and B16_HANDOFF)
         keep(dx, dy)
-        return (dx.reshape(B, N, -1).to(xdt), g["ln1w"], g["ln1b"], g["wqkv"], g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None)
+        out = attach_b16(dx.reshape(B, N, -1).to(xdt), g["dx_b16"])
+        return (out, g["ln1w"], g["ln1b"], g["wqkv"], g["wo"], g["bo"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None, None)
 
 
 class EncoderBlockFn(Function):
@@ -539,8 +574,9 @@ def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq, bq, wkv_s, bkv, wp, bp, 
     return y2, (cls_in.clone() if pack_cls else xi, xj, mu, rs, hn, kv, qb, oc, pr, y, mu2, rs2, h2, z, a)
 
 
-def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, pd=0.0, seeds=(0, 0, 0, 0), wk=None, wv=None):
-    """dy2 fp32 [B, d] -> (dcat fp32 [B*N, d] = grad of the normed concat input, dcls_res fp32 [B, d], grads)."""
+def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, pd=0.0, seeds=(0, 0, 0, 0), wk=None, wv=None, want_dcat_b16=False):
+    """dy2 fp32 [B, d] -> (dcat fp32 [B*N, d] = grad of the normed concat input, dcls_res fp32 [B, d], grads); want_dcat_b16: g["dcat_b16"] is
+    dcat's bf16 copy, written by the same LayerNorm backward (attach_b16)."""
     lowrank = len(saved) == 18                                            # the forward ran the low-rank form: (R, e, rz, S, qf) instead of (kv, p)
     if lowrank:
         xi, xj, mu, rs, hn, R, e, rz, S, qf, q, oc, y, mu2, rs2, h2, z, a = saved
@@ -584,7 +620,7 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
         g["wv"] = ops.head_wgrad(doc, S, H, row_scale=rz[1] if drop else rz, out=_grad_out(wv, (d, d), xi.device))
         g["bv"] = ops.head_bias_grad(doc, rz[2], H) if drop else ops.colsum(doc)
         g["bk"] = bk0                                                              # analytically zero: sum_n ds[n] = 0
-        return _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d, dy)
+        return _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d, dy, want_dcat_b16)
     # the reference's literal order (XVIT_XATTN_FORM=dense, more than 16 heads, head widths other than 64): the K/V projection's
     # gradient through the [B N, 2 d] tensor — a K = 2 d dgrad GEMM, a wgrad GEMM and a column-sum pass
     doc = _dgrad(dyb1, wp_s)
@@ -594,10 +630,10 @@ def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_
     g["bkv"] = ops.colsum(dkv)
     g["wk"], g["wv"] = g["wkv"].split(d, dim=0)
     g["bk"], g["bv"] = g["bkv"].split(d)
-    return _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d, dy)
+    return _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d, dy, want_dcat_b16)
 
 
-def _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d, dy):
+def _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d, dy, want_dcat_b16=False):
     """The query path's gradient joins the CLS rows of dhn, then the LayerNorm over the normed concat."""
     dqb = ops.cast_bf16(dq)
     dhq = _dgrad(dqb, wq_s)                                 # [B, d] bf16: the query path reaches row 0 only
@@ -606,7 +642,7 @@ def _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d,
     hn0 = hn.reshape(B, N * d)[:, :d]
     g["wq"] = _wgrad(dqb, hn0, wq_s)
     g["bq"] = ops.colsum(dq)
-    dcat, _ = ops.layernorm_bwd(dhn, xj, mu, rs, ln1w, g["ln1w"], g["ln1b"], x_alt=xi, seq_len=N)
+    dcat, g["dcat_b16"] = ops.layernorm_bwd(dhn, xj, mu, rs, ln1w, g["ln1w"], g["ln1b"], x_alt=xi, seq_len=N, want_bf16=want_dcat_b16)
     _join_wgrads(xi.device)
     return dcat, dy, g
 
@@ -653,7 +689,9 @@ class CrossFusionFn(Function):
         ln1w, ln2w, wq_s, wkv_s, wp_s, w1_s, w2_s, wk_m, wv_m, *saved = ctx.saved_tensors
         dout = _f32c(dout)
         dy2 = dout[:, 0].contiguous()
-        dcat, dcls_res, g = cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, *ctx.drop, wk=wk_m, wv=wv_m)
+        # a cls-only fusion's patch-row gradient is (up to the CLS rows) the whole gradient of the partner's last block: hand it on in bf16 too
+        dcat, dcls_res, g = cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, *ctx.drop, wk=wk_m, wv=wv_m,
+                                           want_dcat_b16=not concat and B16_HANDOFF)
         dcat = dcat.reshape(B, N, d)
         # cls row -> x_i (normed-concat path + the un-normed residual path); patch rows -> x_j
         if concat:
@@ -665,8 +703,13 @@ class CrossFusionFn(Function):
         else:
             dxi = torch.zeros(B, N, d, dtype=torch.float32, device=dout.device)
         dxi[:, 0] = dcat[:, 0] + dcls_res
+        if getattr(dxi, "_xvit_b16", None) is not None:
+            del dxi._xvit_b16                                  # its CLS rows just changed: a bf16 copy that came with it is stale
         dxj = dcat
         dxj[:, 0] = 0
+        if g["dcat_b16"] is not None:
+            g["dcat_b16"].view(B, N, d)[:, 0] = 0
+            dxj = attach_b16(dxj, g["dcat_b16"])
         wk, wv, bk, bv = g["wk"], g["wv"], g["bk"], g["bv"]
         keep(dxi, dxj, dout)
         return (dxi, dxj, g["ln1w"], g["ln1b"], g["wq"], g["bq"], wk, bk, wv, bv, g["wp"], g["bp"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None, None, None)

@@ -532,6 +532,15 @@ def cast_bf16(src, out=None):
     return out
 
 
+def add_cast(a, b):
+    """-> (a + b fp32, its bf16 copy) in one pass (xvit_add_cast_f32_bf16); contiguous fp32 tensors of one shape, numel % 8 == 0."""
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    out = torch.empty_like(a)
+    outb = torch.empty(a.shape, dtype=torch.bfloat16, device=a.device)
+    _run("add_cast", a.numel() * 14.0, "byte", lambda: _lib.load().xvit_add_cast_f32_bf16(_ptr(a), _ptr(b), _ptr(out), _ptr(outb), a.numel(), _stream()), "xvit_add_cast_f32_bf16")
+    return out, outb
+
+
 def colsum(x, out=None, accumulate=False):
     rows, n = x.shape
     if out is None:

@@ -287,6 +287,9 @@ int xvit_embed_bwd(const float* dx, float* dpos, float* dcls, int MB, int N, int
 
 /* ---- elementwise / reductions --------------------------------------------------------- */
 int xvit_cast_f32_bf16(const float* src, void* dst_bf16, int64_t n, xvit_stream_t stream);
+/* out = a + b (fp32) and its bf16 copy in one pass: the sum of a branch output's two gradients (one per reader: its own fusion and the
+ * partner's, model_cross.py:140-142) handed to the block before it in both dtypes.  n % 8 == 0; out may be a or b. */
+int xvit_add_cast_f32_bf16(const float* a, const float* b, float* out, void* out_bf16, int64_t n, xvit_stream_t stream);
 /* out[n] (+)= sum_r x[r, n];  x bf16 or fp32.  workspace (optional, xvit_colsum_workspace_bytes(rows, n) bytes): the row chunks'
  * partial sums are stored there and added in chunk order (bit-reproducible) instead of meeting in fp32 atomics on out. */
 int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, int n, int accumulate, float* workspace, int64_t workspace_bytes,

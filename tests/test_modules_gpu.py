@@ -614,3 +614,38 @@ def test_fusion_form_is_chosen_by_where_the_bound_is(monkeypatch):
     assert not XF._xattn_lowrank_ok(12, 768, 126 * 513)
     monkeypatch.setattr(XF, "XATTN_FORM", "lowrank")
     assert XF._xattn_lowrank_ok(12, 768, 513)
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_gradient_handoff_in_bf16_changes_no_bit_and_saves_the_casts(monkeypatch, name):
+    """A block's backward starts by casting its incoming gradient to bf16; the node that produced the gradient (the next block's LayerNorm
+    backward, a cls-only fusion's, the fan-out sum) can write that copy in the pass it makes anyway (functional.attach_b16).  Same values
+    rounded once either way: logits and every gradient are bit-identical with the hand-off on and off (fixed-order reductions), and the
+    number of stand-alone cast launches drops."""
+    import xvit
+    import xvit.functional as XF
+    from xvit import ops
+    cfg = R.make_config(name)
+    sd = R.make_state_dict(cfg, seed=2)
+    img, labels = R.make_inputs(cfg, 8, seed=2)      # d-column counts and rows that keep numel % 8 == 0
+    res = {}
+    ops.set_deterministic(True)
+    try:
+        for on in (True, False):
+            monkeypatch.setattr(XF, "B16_HANDOFF", on)
+            model = xvit.ModelCross(cfg).to(dev())
+            model.load_state_dict(sd)
+            model.train()
+            monkeypatch.setattr(ops, "PROFILE", [])
+            logits, loss = model(img.to(dev()), labels.to(dev()))
+            loss.backward()
+            torch.cuda.synchronize()
+            fam = [e[0] for e in ops.PROFILE]
+            monkeypatch.setattr(ops, "PROFILE", None)
+            res[on] = (logits.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()}, fam.count("cast_f32_bf16"), fam.count("add_cast"))
+    finally:
+        ops.set_deterministic(False)
+    assert torch.equal(res[True][0], res[False][0])
+    for k, g in res[True][1].items():
+        assert torch.equal(g, res[False][1][k]), k
+    assert res[True][2] < res[False][2] and res[False][3] == 0, (res[True][2:], res[False][2:])
