@@ -97,6 +97,33 @@ __global__ void add_cast_kernel(const float* __restrict__ a, const float* __rest
   }
 }
 
+// dst[r, :] (and dst2[r, :]) = a[r, :] + b[r, :] over `rows` rows of d columns; a missing operand is zero; every tensor has its own
+// dtype and row stride (the B CLS rows of a [B, N, d] token tensor are rows of stride N d).  One block per row.  The CLS-row
+// bookkeeping of the fusions (model_cross.py:140-142: split off / re-attach the CLS token, and the same on the gradients) in ONE launch
+// per site instead of 2-4 strided torch copies / adds.  dst may be a or b.
+template <typename T>
+__device__ __forceinline__ float ld1(const void* p, int64_t i) {
+  if constexpr (sizeof(T) == 4) return ((const float*)p)[i];
+  else return bf2f(((const bf16*)p)[i]);
+}
+__device__ __forceinline__ float ld_dt(const void* p, int dt, int64_t i) { return dt == XVIT_F32 ? ld1<float>(p, i) : ld1<bf16>(p, i); }
+__device__ __forceinline__ void st_dt(void* p, int dt, int64_t i, float v) {
+  if (dt == XVIT_F32) ((float*)p)[i] = v;
+  else ((bf16*)p)[i] = f2bf(v);
+}
+__global__ __launch_bounds__(256) void rows_combine_kernel(void* __restrict__ dst, int dst_dt, int64_t ld_dst, void* __restrict__ dst2, int dst2_dt, int64_t ld_dst2,
+                                                           const void* a, int a_dt, int64_t ld_a, const void* b, int b_dt, int64_t ld_b, int d) {
+  const int64_t r = blockIdx.x;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float v = 0.f;
+    if (a) v = ld_dt(a, a_dt, r * ld_a + c);
+    if (b) v += ld_dt(b, b_dt, r * ld_b + c);
+    if (dst_dt == XVIT_BF16) v = bf2f(f2bf(v));      // what the bf16 destination holds is what a second destination gets too
+    st_dt(dst, dst_dt, r * ld_dst + c, v);
+    if (dst2) st_dt(dst2, dst2_dt, r * ld_dst2 + c, v);
+  }
+}
+
 __global__ void zero_f32_kernel(float* __restrict__ p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0.f;
@@ -308,6 +335,16 @@ extern "C" int xvit_add_cast_f32_bf16(const float* a, const float* b, float* out
                "xvit_add_cast_f32_bf16: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, (bf16*)out_bf16, n);
   return check_launch("xvit_add_cast_f32_bf16");
+}
+
+extern "C" int xvit_rows_combine(void* dst, int dst_dtype, int64_t ld_dst, void* dst2, int dst2_dtype, int64_t ld_dst2, const void* a, int a_dtype, int64_t ld_a,
+                                 const void* b, int b_dtype, int64_t ld_b, int rows, int d, xvit_stream_t stream) {
+  XVIT_REQUIRE(dst && rows > 0 && d > 0, "xvit_rows_combine: bad arguments");
+  auto ok = [](int dt) { return dt == XVIT_F32 || dt == XVIT_BF16; };
+  XVIT_REQUIRE(ok(dst_dtype) && (!dst2 || ok(dst2_dtype)) && (!a || ok(a_dtype)) && (!b || ok(b_dtype)), "xvit_rows_combine: dtypes must be XVIT_F32 or XVIT_BF16");
+  XVIT_REQUIRE(ld_dst >= d && (!dst2 || ld_dst2 >= d) && (!a || ld_a >= d) && (!b || ld_b >= d), "xvit_rows_combine: a row stride is smaller than d");
+  hipLaunchKernelGGL(rows_combine_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dst, dst_dtype, ld_dst, dst2, dst2_dtype, ld_dst2, a, a_dtype, ld_a, b, b_dtype, ld_b, d);
+  return check_launch("xvit_rows_combine");
 }
 
 static int colsum_rows_per_block(int rows, int n) {

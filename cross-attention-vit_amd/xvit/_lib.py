@@ -56,6 +56,7 @@ SIGNATURES = {
     "xvit_embed_bwd": [vp, vp, vp, i32, i32, i32, vp],
     "xvit_cast_f32_bf16": [vp, vp, i64, vp],
     "xvit_add_cast_f32_bf16": [vp, vp, vp, vp, i64, vp],
+    "xvit_rows_combine": [vp, i32, i64, vp, i32, i64, vp, i32, i64, vp, i32, i64, i32, i32, vp],
     "xvit_colsum": [vp, i32, i64, vp, i32, i32, i32, vp, i64, vp],
     "xvit_dropout": [vp, vp, i32, i64, f32, u64, vp],
     "xvit_cu_trace": [vp, i32, i32, vp],

@@ -185,9 +185,12 @@ class _FanOut(torch.autograd.Function):
         if narrow is not None:
             if len(gs) == 1 and not total.is_contiguous():
                 total, tb = total.contiguous(), None
-            total[:, :1] += narrow                          # in place: `total` is a fusion's freshly written dcat (this node is its only reader) or the sum above
-            if tb is not None:
-                tb.view(total.shape)[:, :1] = total[:, :1]  # B rows of the bf16 copy follow
+            # in place: `total` is a fusion's freshly written dcat (this node is its only reader) or the sum above; the B rows of the bf16 copy follow
+            if total.is_cuda and total.dtype == torch.float32 and narrow.dtype == torch.float32:
+                XF.ops.rows_combine(total[:, 0], a=total[:, 0], b=narrow[:, 0], dst2=tb.view(total.shape)[:, 0] if tb is not None else None)
+            else:
+                total[:, :1] += narrow
+                tb = None
         XF.keep(total, *gs, narrow)
         if tb is not None:
             total = XF.attach_b16(total, tb)

@@ -569,9 +569,10 @@ def cross_forward(xi, xj, B, N, H, eps, ln1w, ln1b, wq, bq, wkv_s, bkv, wp, bp, 
     y2, _, _ = ops.linear_f32(af, w2, b2, residual=y, dropout=_dp(p, seeds[3]))
     # the backward needs xi only for its CLS rows (row 0 of the normed concat): a packed [B, d] copy when the caller is about
     # to overwrite them in place (CrossFusionFn), else xi itself
+    keep_xi = ops.rows_combine(torch.empty(B, d, dtype=torch.float32, device=xi.device), a=cls_in) if pack_cls else xi
     if lowrank:
-        return y2, (cls_in.clone() if pack_cls else xi, xj, mu, rs, hn, *kv, qb, oc, y, mu2, rs2, h2, z, a)
-    return y2, (cls_in.clone() if pack_cls else xi, xj, mu, rs, hn, kv, qb, oc, pr, y, mu2, rs2, h2, z, a)
+        return y2, (keep_xi, xj, mu, rs, hn, *kv, qb, oc, y, mu2, rs2, h2, z, a)
+    return y2, (keep_xi, xj, mu, rs, hn, kv, qb, oc, pr, y, mu2, rs2, h2, z, a)
 
 
 def cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, pd=0.0, seeds=(0, 0, 0, 0), wk=None, wv=None, want_dcat_b16=False):
@@ -638,7 +639,7 @@ def _cross_backward_tail(g, dq, dhn, hn, q, xi, xj, mu, rs, ln1w, wq_s, B, N, d,
     dqb = ops.cast_bf16(dq)
     dhq = _dgrad(dqb, wq_s)                                 # [B, d] bf16: the query path reaches row 0 only
     dhn0 = dhn.reshape(B, N * d)[:, :d]
-    dhn0.copy_(dhn0.float() + dhq.float())                  # B rows: merge the two paths into the CLS rows
+    ops.rows_combine(dhn0, a=dhn0, b=dhq)                   # B rows: merge the two paths into the CLS rows (fp32 add, one bf16 rounding)
     hn0 = hn.reshape(B, N * d)[:, :d]
     g["wq"] = _wgrad(dqb, hn0, wq_s)
     g["bq"] = ops.colsum(dq)
@@ -677,7 +678,7 @@ class CrossFusionFn(Function):
         if not concat:
             return y2.reshape(B, 1, d)
         if inplace:
-            xi2.data.reshape(B, N * d)[:, :d].copy_(y2)
+            ops.rows_combine(xi2.data.reshape(B, N * d)[:, :d], a=y2)
             return xi2.reshape(B, N, d)
         out = xi2.clone().reshape(B, N, d)
         out[:, 0] = y2
@@ -688,7 +689,7 @@ class CrossFusionFn(Function):
         B, N, H, d, concat, inplace, narrow = ctx.meta
         ln1w, ln2w, wq_s, wkv_s, wp_s, w1_s, w2_s, wk_m, wv_m, *saved = ctx.saved_tensors
         dout = _f32c(dout)
-        dy2 = dout[:, 0].contiguous()
+        dy2 = ops.rows_combine(torch.empty(B, d, dtype=torch.float32, device=dout.device), a=dout[:, 0])
         # a cls-only fusion's patch-row gradient is (up to the CLS rows) the whole gradient of the partner's last block: hand it on in bf16 too
         dcat, dcls_res, g = cross_backward(dy2, saved, B, N, H, ln1w, wq_s, wkv_s, wp_s, ln2w, w1_s, w2_s, *ctx.drop, wk=wk_m, wv=wv_m,
                                            want_dcat_b16=not concat and B16_HANDOFF)
@@ -702,14 +703,14 @@ class CrossFusionFn(Function):
             dxi = torch.empty(B, 1, d, dtype=torch.float32, device=dout.device)       # xi was the CLS rows alone: so is its gradient
         else:
             dxi = torch.zeros(B, N, d, dtype=torch.float32, device=dout.device)
-        dxi[:, 0] = dcat[:, 0] + dcls_res
+        ops.rows_combine(dxi[:, 0], a=dcat[:, 0], b=dcls_res)
         if getattr(dxi, "_xvit_b16", None) is not None:
             del dxi._xvit_b16                                  # its CLS rows just changed: a bf16 copy that came with it is stale
         dxj = dcat
-        dxj[:, 0] = 0
-        if g["dcat_b16"] is not None:
-            g["dcat_b16"].view(B, N, d)[:, 0] = 0
-            dxj = attach_b16(dxj, g["dcat_b16"])
+        db16 = g["dcat_b16"]
+        ops.rows_combine(dxj[:, 0], dst2=db16.view(B, N, d)[:, 0] if db16 is not None else None)     # the CLS rows belong to x_i: zero here
+        if db16 is not None:
+            dxj = attach_b16(dxj, db16)
         wk, wv, bk, bv = g["wk"], g["wv"], g["bk"], g["bv"]
         keep(dxi, dxj, dout)
         return (dxi, dxj, g["ln1w"], g["ln1b"], g["wq"], g["bq"], wk, bk, wv, bv, g["wp"], g["bp"], g["ln2w"], g["ln2b"], g["w1"], g["b1"], g["w2"], g["b2"], None, None, None, None, None)

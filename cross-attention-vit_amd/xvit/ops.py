@@ -541,6 +541,24 @@ def add_cast(a, b):
     return out, outb
 
 
+def rows_combine(dst, a=None, b=None, dst2=None):
+    """dst[r, :] (and dst2[r, :]) = a[r, :] + b[r, :] (xvit_rows_combine): 2-D views [rows, d] with a unit last stride and any row stride
+    (e.g. t[:, 0] of a [B, N, d] tensor), fp32 or bf16 each; a missing operand is zero; dst may be a or b."""
+    rows, d = dst.shape
+
+    def arg(t):
+        if t is None:
+            return None, 0, 0
+        assert t.shape == (rows, d) and t.stride(1) == 1, f"rows_combine: need [rows, d] views with a unit last stride, got {tuple(t.shape)} {t.stride()}"
+        return _ptr(t), _dt(t), t.stride(0)
+    pd, dd, ld = arg(dst)
+    p2, d2, l2 = arg(dst2)
+    pa, da, la = arg(a)
+    pb, db, lb = arg(b)
+    _run("rows_combine", rows * d * 8.0, "byte", lambda: _lib.load().xvit_rows_combine(pd, dd, ld, p2, d2, l2, pa, da, la, pb, db, lb, rows, d, _stream()), "xvit_rows_combine")
+    return dst
+
+
 def colsum(x, out=None, accumulate=False):
     rows, n = x.shape
     if out is None:

@@ -290,6 +290,12 @@ int xvit_cast_f32_bf16(const float* src, void* dst_bf16, int64_t n, xvit_stream_
 /* out = a + b (fp32) and its bf16 copy in one pass: the sum of a branch output's two gradients (one per reader: its own fusion and the
  * partner's, model_cross.py:140-142) handed to the block before it in both dtypes.  n % 8 == 0; out may be a or b. */
 int xvit_add_cast_f32_bf16(const float* a, const float* b, float* out, void* out_bf16, int64_t n, xvit_stream_t stream);
+/* dst[r, :] (and dst2[r, :], optional) = a[r, :] + b[r, :] for r < rows, d columns; a NULL operand is zero; each tensor has its own dtype
+ * (XVIT_F32 / XVIT_BF16) and row stride in elements.  The CLS-row bookkeeping of the fusions — take the B CLS rows out of a [B, N, d] token
+ * tensor (row stride N d), write the fused token back, add / zero / copy the same rows of the gradients (model_cross.py:140-142 and its
+ * backward) — one launch per site.  dst may alias a or b. */
+int xvit_rows_combine(void* dst, int dst_dtype, int64_t ld_dst, void* dst2, int dst2_dtype, int64_t ld_dst2, const void* a, int a_dtype, int64_t ld_a,
+                      const void* b, int b_dtype, int64_t ld_b, int rows, int d, xvit_stream_t stream);
 /* out[n] (+)= sum_r x[r, n];  x bf16 or fp32.  workspace (optional, xvit_colsum_workspace_bytes(rows, n) bytes): the row chunks'
  * partial sums are stored there and added in chunk order (bit-reproducible) instead of meeting in fp32 atomics on out. */
 int xvit_colsum(const void* x, int x_dtype, int64_t ldx, float* out, int rows, int n, int accumulate, float* workspace, int64_t workspace_bytes,

@@ -30,6 +30,9 @@ def test_argument_errors_do_not_launch():
     assert lib.xvit_linear_f32(None, 0, None, 0, None, None, 0, 4, 8, 24, 0, None, 0, None, 0, None, 0, 0.0, 0, None, 0, None) < 0
     assert lib.xvit_linear_f32_workspace_bytes(126, 768, 3072) > 0 and lib.xvit_linear_f32_workspace_bytes(0, 8, 16) == 0
     assert lib.xvit_set_option(b"no_such_option", 1) < 0 and lib.xvit_set_option(b"gemm_tile", 0) == 0
+    assert lib.xvit_rows_combine(64, 1, 100, None, 0, 0, 64, 1, 768, None, 0, 0, 8, 768, None) < 0 and b"row stride" in lib.xvit_last_error_string()
+    assert lib.xvit_rows_combine(64, 7, 768, None, 0, 0, None, 0, 0, None, 0, 0, 8, 768, None) < 0          # unknown dtype
+    assert lib.xvit_add_cast_f32_bf16(64, 64, 64, 64, 12, None) < 0                                       # n not a multiple of 8
 
 
 def test_attention_workspaces_and_peel_predicate():

@@ -329,3 +329,36 @@ def test_xattn_kv_dgrad_from_rank_one_coefficients(B, N, H):
     ops.head_rows(do.to(dev()), gw[d:].contiguous(), Rm[H:].transpose(0, 1), H)
     dhn = ops.xattn_kv_dgrad(coef, Rm, B, N, H, d)
     assert_close(dhn, (dense @ wkv.double()).float(), "dhn = dkv Wkv")
+
+
+def test_rows_combine_all_dtype_and_stride_combinations():
+    """xvit_rows_combine: the CLS-row bookkeeping of the fusions (copy out / write back / add / zero the B CLS rows of a [B, N, d] tensor,
+    fp32 or bf16, optionally into two destinations) against torch indexing — bit-exact."""
+    ops = _ops()
+    B, N, d = 5, 7, 200
+    g = torch.Generator().manual_seed(0)
+    tok = torch.randn(B, N, d, generator=g).to(dev())
+    tokb = torch.randn(B, N, d, generator=g).to(dev()).bfloat16()
+    vec = torch.randn(B, d, generator=g).to(dev())
+    vecb = torch.randn(B, d, generator=g).to(dev()).bfloat16()
+    # copy the CLS rows out (strided source, packed destination)
+    out = ops.rows_combine(torch.empty(B, d, device=dev()), a=tok[:, 0])
+    assert torch.equal(out, tok[:, 0])
+    # write rows back in place of the CLS rows; the rest of the tensor is untouched
+    t2 = tok.clone()
+    ops.rows_combine(t2.reshape(B, N * d)[:, :d], a=vec)
+    assert torch.equal(t2[:, 0], vec) and torch.equal(t2[:, 1:], tok[:, 1:])
+    # strided = strided + packed, second destination in bf16
+    t3, t3b = tok.clone(), tokb.clone()
+    ops.rows_combine(t3[:, 0], a=t3[:, 0], b=vec, dst2=t3b[:, 0])
+    assert torch.equal(t3[:, 0], tok[:, 0] + vec) and torch.equal(t3b[:, 0], (tok[:, 0] + vec).bfloat16()) and torch.equal(t3b[:, 1:], tokb[:, 1:])
+    # bf16 += bf16 through fp32, one rounding
+    t4 = tokb.clone()
+    ops.rows_combine(t4.reshape(B, N * d)[:, :d], a=t4.reshape(B, N * d)[:, :d], b=vecb)
+    assert torch.equal(t4[:, 0], (tokb[:, 0].float() + vecb.float()).bfloat16())
+    # zero rows in both dtypes
+    t5, t5b = tok.clone(), tokb.clone()
+    ops.rows_combine(t5[:, 0], dst2=t5b[:, 0])
+    assert float(t5[:, 0].abs().max()) == 0.0 and float(t5b[:, 0].float().abs().max()) == 0.0 and torch.equal(t5[:, 1:], tok[:, 1:])
+    with pytest.raises(AssertionError):
+        ops.rows_combine(tok[:, :, 0], a=vec[:, :N])      # last stride must be one
