@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define XVIT_VERSION 302 /* 0.3.2: probability dropout in the low-rank fusion (xvit_cls_softmax_*, xvit_head_cols bias_scale, xvit_head_bias_grad), xvit_xattn_kv_wgrad removed; 0.3.1: xvit_set_dropout_epoch; 0.3.0: workspaces in xvit_attn_fwd/bwd (CLS peel), xvit_linear_f32_batched; 0.2.0: ld_alt in xvit_layernorm_fwd/bwd, dropout in xvit_attn_*, xvit_patch_embed_*, xvit_attn_fwd_fp8, xvit_linear_f32, workspaces */
+#define XVIT_VERSION 303 /* 0.3.3: xvit_add_cast_f32_bf16, xvit_rows_combine; 0.3.2: probability dropout in the low-rank fusion (xvit_cls_softmax_*, xvit_head_cols bias_scale, xvit_head_bias_grad), xvit_xattn_kv_wgrad removed; 0.3.1: xvit_set_dropout_epoch; 0.3.0: workspaces in xvit_attn_fwd/bwd (CLS peel), xvit_linear_f32_batched; 0.2.0: ld_alt in xvit_layernorm_fwd/bwd, dropout in xvit_attn_*, xvit_patch_embed_*, xvit_attn_fwd_fp8, xvit_linear_f32, workspaces */
 
 enum { XVIT_OK = 0, XVIT_ERR_ARG = -1, XVIT_ERR_UNSUPPORTED = -2 };
 enum { XVIT_BF16 = 0, XVIT_F32 = 1 };
