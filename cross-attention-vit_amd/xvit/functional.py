@@ -346,18 +346,27 @@ def _masked(t_b, p, seed):
 # LayerNorm gradients, dpos, dcls, ...).  ModelCross.forward opens a fresh 4 MB arena (one fill, on the caller's stream, before any fork: it
 # happens-before every backward kernel); _zeros() hands out 256-byte aligned slices of it and falls back to torch.zeros when it is used up.
 # A slice is never handed out twice; gradients that ARE slices keep the arena's storage alive as long as they live.
-_ARENA = [None, 0]
+# An arena is only used in the regime it was opened in: one opened eagerly is not touched by a HIP-graph capture (its fill would not be
+# part of the graph: replays would accumulate into memory zeroed once), and one opened inside a capture lives in that graph's pool
+# (xvit.graph.GraphedStep drops it when the capture ends).  A model that never opens one (any module used outside ModelCross / ModelVIT)
+# gets torch.zeros per request.
+_ARENA = [None, 0, False]
 ARENA_FLOATS = 1 << 20
 
 
 def arena_begin(device):
     _ARENA[0] = torch.zeros(ARENA_FLOATS, dtype=torch.float32, device=device)
     _ARENA[1] = 0
+    _ARENA[2] = torch.cuda.is_current_stream_capturing()
+
+
+def arena_reset():
+    _ARENA[0] = None
 
 
 def _zeros(n, ref, shape=None):
     a = _ARENA[0]
-    if a is not None and a.device == ref.device and _ARENA[1] + n <= a.numel():
+    if a is not None and a.device == ref.device and _ARENA[1] + n <= a.numel() and _ARENA[2] == torch.cuda.is_current_stream_capturing():
         o = _ARENA[1]
         _ARENA[1] = o + (n + 63) // 64 * 64
         out = a[o:o + n]

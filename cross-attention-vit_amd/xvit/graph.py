@@ -86,10 +86,12 @@ class GraphedStep:
             self.graph = torch.cuda.CUDAGraph()
             for p in self.params:
                 p.grad = None                      # gradients are (re)allocated from the graph's private pool
+            XF.arena_reset()                       # no zero arena crosses the capture boundary in either direction (functional._zeros)
             try:
                 with torch.cuda.graph(self.graph):
                     self.logits, self.loss = self._eager(zero=False)
             finally:
+                XF.arena_reset()
                 XF.release_capture_keep()         # tensors that crossed streams were kept alive up to here (functional.keep)
             if reducer is not None:
                 for p in self.params:              # from now on p.grad IS the bucket view the graph's collectives reduce in place

@@ -66,6 +66,8 @@ class ModelVIT(EpochStatsMixin, _Base):
         self.initialize_model()
 
     def forward(self, img, labels):
+        if img.is_cuda and torch.is_grad_enabled():
+            XF.arena_begin(img.device)                   # the backward's small zeroed vectors: one fill per step (functional._zeros)
         x = XF.PatchEmbedFn.apply(img, self.patch_to_embedding.weight, self.patch_to_embedding.bias, self.cls_token, self.pos_embedding,
                                   self.patch_size, _p(self, self.dropout), True)
         x = self.transformer(x)

@@ -157,3 +157,76 @@ def test_graphed_step_with_dropout_draws_new_masks_per_replay_and_matches_eager_
     a, _ = model(img, lab)
     b, _ = model(img, lab)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_graphed_step_of_model_vit(p):
+    """The reference's second model (modelv3.ModelVIT, main_mist.py:87 with params_list2: dropout 0.1) as a captured step: without dropout a
+    replay reproduces the eager gradients; with the reference's rate the replays draw different masks and every gradient stays finite."""
+    import xvit
+    from xvit.graph import GraphedStep
+    cfg = R.make_config("small", num_layers=2, dropout=p)
+    sd = R.make_vit_state_dict(cfg, seed=11)
+    model = xvit.ModelVIT(cfg).to(dev())
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    ins = [tuple(t.to(dev()) for t in R.make_inputs(cfg, 3, seed=s)) for s in (4, 6)]
+    torch.manual_seed(7)
+    step = GraphedStep(model, *ins[0])
+    if p == 0.0:
+        for which in (0, 1, 0):
+            for q in model.parameters():
+                q.grad = None
+            logits_e, loss_e = model(*ins[which])
+            loss_e.backward()
+            ref = {k: q.grad.clone() for k, q in model.named_parameters()}
+            logits, loss = step(*ins[which])
+            torch.cuda.synchronize()
+            assert torch.equal(logits, logits_e.detach()) and float(loss) == float(loss_e.detach())
+            for k, q in model.named_parameters():
+                assert rel(q.grad, ref[k]) < 1e-5 or float(ref[k].abs().max()) < 1e-6, (which, k)
+    else:
+        l1 = step(*ins[0])[0].clone()
+        l2 = step(*ins[0])[0].clone()
+        torch.cuda.synchronize()
+        assert not torch.equal(l1, l2)
+        assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in model.parameters())
+
+
+def test_capture_of_a_model_that_opens_no_zero_arena():
+    """The backward chains accumulate bias / LayerNorm gradients into zeroed vectors.  ModelCross and ModelVIT open a zero arena per step
+    (functional.arena_begin, one fill); any other composition of the module classes — here a bare nn.Sequential of SelfAttentionBlocks under
+    a loss — does not, and a capture must then zero per request INSIDE the graph instead of slicing an arena an earlier eager forward
+    filled once (replays would accumulate into it: the second replay's LayerNorm gradients came out doubled)."""
+    import xvit
+    cfg = R.make_config("small")
+    # leave a stale eager arena behind, as an earlier ModelCross step in the same process does
+    warm = xvit.ModelCross(cfg).to(dev())
+    warm(*[t.to(dev()) for t in R.make_inputs(cfg, 2, seed=1)])[1].backward()
+    torch.manual_seed(3)
+    blocks = torch.nn.Sequential(xvit.SelfAttentionBlock(cfg), xvit.SelfAttentionBlock(cfg)).to(dev())
+    x = torch.randn(2, 65, cfg.hidden_dim, device=dev())
+
+    def run():
+        for q in blocks.parameters():
+            q.grad = None
+        blocks(x).square().mean().backward()
+
+    run()
+    torch.cuda.synchronize()
+    ref = {k: q.grad.clone() for k, q in blocks.named_parameters()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    for q in blocks.parameters():
+        q.grad = None
+    with torch.cuda.graph(g):
+        blocks(x).square().mean().backward()
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    for k, q in blocks.named_parameters():
+        assert rel(q.grad, ref[k]) < 1e-5 or float(ref[k].abs().max()) < 1e-6, k
