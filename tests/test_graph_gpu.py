@@ -230,3 +230,44 @@ def test_capture_of_a_model_that_opens_no_zero_arena():
     torch.cuda.synchronize()
     for k, q in blocks.named_parameters():
         assert rel(q.grad, ref[k]) < 1e-5 or float(ref[k].abs().max()) < 1e-6, k
+
+
+def test_two_captured_models_and_eager_steps_do_not_share_state():
+    """Process-wide pieces (zero arena, capture keep-list, flat weight buffers, stream pools) must not leak between two captured steps of
+    different models, nor into eager steps run afterwards: replay A, B, A, B, then eager A and B — every gradient as in the eager reference."""
+    import xvit
+    from xvit.graph import GraphedStep
+    cfg_a, cfg_b = R.make_config("tiny"), R.make_config("small", num_layers=2)
+    a = xvit.ModelCross(cfg_a).to(dev())
+    a.load_state_dict(R.make_state_dict(cfg_a, seed=0))
+    b = xvit.ModelVIT(cfg_b).to(dev())
+    b.load_state_dict(R.make_vit_state_dict(cfg_b, seed=11))
+    a.train(); b.train()
+    in_a = tuple(t.to(dev()) for t in R.make_inputs(cfg_a, 4, seed=0))
+    in_b = tuple(t.to(dev()) for t in R.make_inputs(cfg_b, 3, seed=4))
+
+    def eager(m, ins):
+        for q in m.parameters():
+            q.grad = None
+        logits, loss = m(*ins)
+        loss.backward()
+        return logits.detach().clone(), {k: q.grad.clone() for k, q in m.named_parameters()}
+
+    ref_a, ref_b = eager(a, in_a), eager(b, in_b)
+    step_a = GraphedStep(a, *in_a)
+    step_b = GraphedStep(b, *in_b)
+
+    def check(m, ref, logits):
+        torch.cuda.synchronize()
+        assert torch.equal(logits, ref[0])
+        for k, q in m.named_parameters():
+            assert rel(q.grad, ref[1][k]) < 1e-5 or float(ref[1][k].abs().max()) < 1e-6, k
+
+    for _ in range(2):
+        check(a, ref_a, step_a(*in_a)[0])
+        check(b, ref_b, step_b(*in_b)[0])
+    la, ga = eager(a, in_a)
+    check(a, ref_a, la)
+    lb, gb = eager(b, in_b)
+    check(b, ref_b, lb)
+    check(a, ref_a, step_a(*in_a)[0])
