@@ -383,9 +383,13 @@ class ModelCross(EpochStatsMixin, _Base):
             nxt = None if last else self.transformer[k + 1]
             sole = not observed and (last or all(len(b) > 0 for b in nxt.blocks))
             x = blk(x, cls_only=last and not observed, exclusive=sole)
-        per_mod = [XF.HeadFn.apply(x[m], self.norm[m].weight, self.norm[m].bias, self.mlp_head[m][0].weight, self.mlp_head[m][0].bias,
-                                   self.mlp_head[m][3].weight, self.mlp_head[m][3].bias, self.norm[m].eps, _p(self, self.mlp_head[m][2]))
-                   for m in range(self.num_modalities)]
+        heads = [(lambda m=m: XF.HeadFn.apply(x[m], self.norm[m].weight, self.norm[m].bias, self.mlp_head[m][0].weight, self.mlp_head[m][0].bias,
+                                              self.mlp_head[m][3].weight, self.mlp_head[m][3].bias, self.norm[m].eps, _p(self, self.mlp_head[m][2])))
+                 for m in range(self.num_modalities)]
+        if len(self.transformer) > 0 and os.environ.get("XVIT_HEAD_STREAMS", "0") == "1":    # experiment: each head on its modality's stream
+            per_mod = self.transformer[-1]._parallel(heads, list(x), kind="fusion")
+        else:
+            per_mod = [h() for h in heads]
         logits, loss = XF.MeanCrossEntropyFn.apply(torch.stack(per_mod), labels, self.label_smoothing)
         return logits, loss
 
